@@ -1,0 +1,152 @@
+"""bench.py — OAKE images/sec for ViT-B/32 encode_image at 224^2, batch 256 per GPU.
+
+A "step" is one pass of the hot path (oadp.oake.globals' encode_image + fused L2-normalise + fp16
+cast) over one batch of 256 synthetic device-resident 3x224x224 crops, random-init ViT-B/32 weights.
+Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU, images sharded, no data-path
+collective; RCCL only for the barrier, the max-over-ranks time and the counters gather.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+FLOP_PER_IMAGE = 8_817_623_040          # BASELINE.md §3 (2 FLOP/MAC; LN/softmax/GELU/bias excluded)
+PEAK_MFMA_DENSE = 2.5e15                # MI355X bf16/f16 dense (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(sd, seconds: float = 12.0) -> dict:
+    """The oracle's fp32 torch-CPU encode_image (a PORT/restatement: the reference's `clip` fork is
+    not importable anywhere — SURVEY.md §8c) on a bounded sample of the same workload."""
+    from oadp_amd.weights import synthetic_images
+    from oracle.vit_ref import ViTConfig, encode_image_ref, l2_normalize
+    bs = 32
+    x = synthetic_images(bs, seed=5)
+    cfg = ViTConfig()
+    threads = torch.get_num_threads()
+    l2_normalize(encode_image_ref(sd, cfg, x[:4]))  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        l2_normalize(encode_image_ref(sd, cfg, x)).half()
+        n += bs
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 256:
+            break
+    return {'value': round(n / dt, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} synthetic 3x224x224 images in batches of {bs}, fp32 torch-CPU oracle, '
+                      f'{dt:.1f} s'}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--dtype', choices=['f16', 'bf16'], default=os.environ.get('OAKE_DTYPE', 'f16'))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    dist = world > 1
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dev = torch.device('cuda', local % torch.cuda.device_count())
+    if dist:
+        import torch.distributed as td
+        td.init_process_group(backend='nccl')  # RCCL on ROCm
+
+    from oadp_amd import clip
+    from oadp_amd.weights import synthetic_state_dict
+    cdt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
+    sd = synthetic_state_dict()
+    model, _ = clip.load(sd, compute_dtype=cdt, max_batch=args.batch)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(args.batch, 3, 224, 224, generator=g, device=dev)  # resident in HBM
+
+    def step():
+        return model.encode_image(images, normalize=True, out_dtype=torch.float16)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+
+    counters = torch.tensor([args.batch * args.steps, args.batch * args.steps, elapsed,
+                             out.numel() * 2 * args.steps], dtype=torch.float64, device=dev)
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = tmax.item()
+        gathered = [torch.zeros_like(counters) for _ in range(world)]
+        td.all_gather(gathered, counters)  # the one RCCL exchange: 32 B per rank
+        total_images = sum(c[0].item() for c in gathered)
+    else:
+        total_images = counters[0].item()
+
+    roofline = None
+    kernels = None
+    if rank == 0 and not args.no_profile:
+        model.visual.profile(True)
+        for _ in range(3):
+            step()
+        prof = model.visual.profile_read()
+        model.visual.profile(False)
+        gemms = [p for p in prof if p['flops'] > 0 and p['name'].startswith('gemm')]
+        dom = max(gemms, key=lambda p: p['total_ms'])
+        achieved = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+        roofline = {
+            'bound': 'mfma', 'kernel': dom['name'],
+            'achieved': round(achieved, 1), 'peak': PEAK_MFMA_DENSE / 1e12, 'unit': 'TFLOP/s',
+            'frac': round(achieved * 1e12 / PEAK_MFMA_DENSE, 4),
+            'avg_launch_us': round(dom['total_ms'] * 1e3 / dom['launches'], 2),
+            'traffic': None,
+        }
+        tot_ms = sum(p['total_ms'] for p in prof)
+        kernels = {p['name']: {'ms_per_step': round(p['total_ms'] / 3, 4),
+                               'share': round(p['total_ms'] / tot_ms, 4),
+                               'tflops': round(p['flops'] / (p['total_ms'] * 1e-3) / 1e12, 1) if p['flops'] else None}
+                   for p in sorted(prof, key=lambda p: -p['total_ms'])}
+
+    if rank == 0:
+        value = total_images / elapsed
+        line = {
+            'metric': 'OAKE images/sec (ViT-B/32, 224^2, bs256)', 'value': round(value, 1),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'oadp.oake.globals: ViT-B/32 encode_image + L2-normalise + fp16, '
+                                   f'single 224^2 crop per image, batch {args.batch} per GPU, '
+                                   'random-init weights, device-resident N(0,1) inputs',
+                       'batch_per_gpu': args.batch, 'sharding': f'images x{world} (no data-path collective)'},
+            'mfma_roofline_frac_e2e': round(value / world * FLOP_PER_IMAGE / PEAK_MFMA_DENSE, 4),
+            'roofline': roofline,
+            'kernels': kernels,
+            'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(sd),
+        }
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

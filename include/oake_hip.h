@@ -1,0 +1,199 @@
+/*
+ * oake_hip.h — C ABI of liboake_hip.so: the MI355X (gfx950) implementation of OADP's
+ * OAKE CLIP image-encoder hot path.
+ *
+ * The reference (LutingWang/OADP) has no native FFI for this path: it sits behind two
+ * Python-level boundaries.  This header is the C boundary that the
+ * Python host layer (oadp_amd/clip/model.py) binds with ctypes; each entry point names
+ * the reference interface it replaces.
+ *
+ *   reference call site                                   -> entry point here
+ *   ---------------------------------------------------------------------------
+ *   clip.load_default(...)            oadp/oake/globals.py:47, blocks.py:123,
+ *                                     objects.py:290       -> oake_create + oake_load_tensor*
+ *   model.encode_image(image)         oadp/oake/globals.py:57, blocks.py:129
+ *                                                          -> oake_encode_image
+ *   model.visual(objects, masks)      oadp/oake/objects.py:330 (+ Hooks, objects.py:198-266,
+ *     after Validator._build_model      surgery objects.py:285-314)
+ *                                                          -> oake_encode_objects
+ *   F.normalize(embedding).half()     oadp/oake/globals.py:58-59, blocks.py:130-132,
+ *                                     objects.py:331,334   -> `normalize` / `out_dtype` args
+ *   preprocess(image.crop(box))       oadp/oake/blocks.py:79-81, objects.py:116-127
+ *                                                          -> oake_crop_normalize
+ *
+ * Conventions: plain C, int status (0 = OAKE_OK), no exception crosses the ABI.  All data
+ * pointers named d_* are DEVICE pointers owned by the caller (e.g. a torch tensor's
+ * data_ptr()); pointers named h_* are host pointers.  Work is enqueued on the hipStream_t
+ * passed as `stream` (an opaque void* here so the header needs no HIP include; 0 = the
+ * null stream).  A handle is bound to one device, owns weights + workspace, and is not
+ * thread-safe (the reference runs one process per GPU and calls the model only from the
+ * main thread: oadp/oake/base.py:122-126).
+ */
+#ifndef OAKE_HIP_H_
+#define OAKE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OAKE_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define OAKE_API __attribute__((visibility("default")))
+#else
+#define OAKE_API
+#endif
+
+/* status codes */
+enum {
+  OAKE_OK = 0,
+  OAKE_ERR_INVALID = 1,   /* bad argument / shape / dtype */
+  OAKE_ERR_HIP = 2,       /* a HIP runtime call failed; see oake_last_error */
+  OAKE_ERR_STATE = 3,     /* e.g. encode before all weights were loaded */
+  OAKE_ERR_UNKNOWN_TENSOR = 4
+};
+
+/* element types for image inputs / embedding outputs */
+enum {
+  OAKE_F32 = 0,
+  OAKE_F16 = 1,
+  OAKE_BF16 = 2,
+  OAKE_U8 = 3
+};
+
+typedef struct oake_handle oake_handle;
+
+/*
+ * Architecture + patch-embedding geometry.  ViT-B/32 defaults: image 224,
+ * patch 32, width 768, layers 12, heads 12 (head_dim must be 64), mlp 3072, embed 512.
+ * `stride`/`padding` describe conv1: 32/0 for encode_image; objects mode uses the
+ * reference's surgery (oadp/oake/objects.py:298-301): stride = 32 // upsample = 16,
+ * padding = (32 - 1) // 2 = 15, which makes grid = 14 and 197 tokens.
+ * `compute_dtype`: OAKE_F16 (reference GPU dtype, default) or OAKE_BF16 — the 16-bit type fed
+ * to the MFMA units; accumulation, LayerNorm, softmax and the residual stream are fp32.
+ */
+typedef struct oake_config {
+  int32_t image_size;
+  int32_t patch_size;
+  int32_t stride;
+  int32_t padding;
+  int32_t width;
+  int32_t layers;
+  int32_t heads;
+  int32_t mlp_dim;
+  int32_t embed_dim;
+  int32_t compute_dtype;
+  int32_t max_batch;      /* workspace is sized for this many crops per internal pass */
+  int32_t reserved;
+} oake_config;
+
+OAKE_API uint32_t oake_abi_version(void);
+
+/* Fill *cfg with ViT-B/32 defaults (stride 32, padding 0, f16, max_batch 256). */
+OAKE_API void oake_default_config(oake_config* cfg);
+
+/* Create a handle on HIP device `device`.  Allocates weights + workspace. */
+OAKE_API int oake_create(const oake_config* cfg, int device, oake_handle** out);
+OAKE_API void oake_destroy(oake_handle* h);
+
+/* Last error text for this handle (or for a failed oake_create when h == NULL). */
+OAKE_API const char* oake_last_error(const oake_handle* h);
+
+/* Derived geometry: grid = (image + 2*padding - patch)/stride + 1, tokens = grid*grid + 1. */
+OAKE_API int oake_grid(const oake_handle* h);
+OAKE_API int oake_tokens(const oake_handle* h);
+
+/*
+ * Upload one tensor of the OpenAI-CLIP state_dict by its key (the same keys the reference's
+ * `clip` package loads, SURVEY.md §7 hard part 1), e.g. "visual.conv1.weight",
+ * "visual.class_embedding", "visual.positional_embedding" (must have oake_tokens() rows —
+ * the host interpolates it for objects mode as objects.py:292-296 does), "visual.ln_pre.weight",
+ * "visual.transformer.resblocks.3.attn.in_proj_weight", ..., "visual.ln_post.bias",
+ * "visual.proj".  `h_data` is a HOST pointer to `numel` contiguous fp32 values in the
+ * state_dict's own layout.  Synchronous.  Keys outside the vision tower are rejected with
+ * OAKE_ERR_UNKNOWN_TENSOR.
+ */
+OAKE_API int oake_load_tensor(oake_handle* h, const char* name, const float* h_data, size_t numel);
+
+/* Number of tensors still missing before encode may be called (0 = ready). */
+OAKE_API int oake_missing_tensors(const oake_handle* h);
+
+/*
+ * model.encode_image(images): d_images is [n,3,image,image] NCHW contiguous of `in_dtype`
+ * (OAKE_F32 | OAKE_F16 | OAKE_BF16), already CLIP-normalised.  d_out is [n,embed_dim] of
+ * `out_dtype` (OAKE_F32 | OAKE_F16).  normalize != 0 fuses the callers'
+ * F.normalize(embedding) (L2 over dim 1, eps 1e-12) before the output cast.
+ * n may exceed max_batch (processed in passes).  n == 0 is a no-op.
+ */
+OAKE_API int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
+                      void* d_out, int out_dtype, int normalize, void* stream);
+
+/*
+ * model.visual(objects, masks) after the reference's objects-mode surgery + Hooks: the
+ * object-token stream y is returned (ln_post + proj applied).  Requires stride/padding such
+ * that grid*grid == mask elements per crop.  d_masks is [n,1,grid,grid] of `mask_dtype`
+ * (OAKE_F32 | OAKE_F16), 1 = background, 0 = object (objects.py:129-155); the additive
+ * attention bias is -100*mask for patch keys and 0 for the object token itself
+ * (objects.py:209-213).
+ */
+OAKE_API int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype,
+                        const void* d_masks, int mask_dtype, int n,
+                        void* d_out, int out_dtype, int normalize, void* stream);
+
+/*
+ * GPU half of `preprocess(image.crop(box))` for crops that need no resampling or bilinear /
+ * bicubic resampling of a uint8 HWC (interleaved RGB) device image: for each of k boxes
+ * (x1,y1,x2,y2 int32, PIL crop semantics: zero fill outside the image) produce a
+ * [k,3,out,out] NCHW tensor of `out_dtype`, scaled by 1/255 and normalised with mean/std
+ * (3 floats each, host pointers).  When the box is exactly out×out the result is bit-exact
+ * w.r.t. ToTensor+Normalize in fp32.
+ */
+OAKE_API int oake_crop_normalize(oake_handle* h, const uint8_t* d_image_hwc, int height, int width,
+                        const int32_t* d_boxes_xyxy, int k, int out_size,
+                        const float* h_mean3, const float* h_std3,
+                        void* d_out, int out_dtype, void* stream);
+
+/*
+ * Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
+ * enable=1 brackets every kernel launch with events; oake_profile_read synchronises and
+ * returns, for up to `cap` kernel slots, name / total milliseconds / launch count / flops.
+ * Profiling serialises launches — never leave it on inside a throughput measurement.
+ */
+typedef struct oake_profile_entry {
+  char name[48];
+  double total_ms;
+  double flops;      /* algorithmic FLOPs summed over the launches (2 per MAC), 0 for non-GEMM */
+  double bytes;      /* algorithmic bytes summed over the launches (HBM-bound kernels) */
+  int64_t launches;
+} oake_profile_entry;
+
+OAKE_API int oake_profile_enable(oake_handle* h, int enable);
+OAKE_API int oake_profile_read(oake_handle* h, oake_profile_entry* entries, int cap, int* count);
+OAKE_API int oake_profile_reset(oake_handle* h);
+
+/*
+ * Kernel-level debug/test entry points (used by tests/ to check each kernel against the
+ * oracle; not needed by a reference-side integration).  All pointers are device pointers.
+ * dtype16 = OAKE_F16 | OAKE_BF16 selects the 16-bit operand type.
+ */
+/* C[m,n] = A[m,k] * W[n,k]^T + bias[n] (fp32 out).  A, W are 16-bit row-major. */
+OAKE_API int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bias, float* d_c,
+                    int m, int n, int k, int dtype16, void* stream);
+/* y = LayerNorm(x) over last dim `c` (eps 1e-5), x fp32 [rows,c] -> y 16-bit [rows,c]. */
+OAKE_API int oake_debug_layernorm(const float* d_x, const float* d_gamma, const float* d_beta,
+                         void* d_y, int rows, int c, int dtype16, void* stream);
+/* Multi-head self-attention on packed qkv [n*l, 3*heads*64] (q pre-scaled), -> [n*l, heads*64]. */
+OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads,
+                         int dtype16, void* stream);
+/* Raw ds_read_b64_tr_b16 semantics probe: in = 256 uint16, out = 64 lanes x 4 uint16. */
+OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
+/* Attention V-fragment path: 0 = 16-bit LDS gathers, 1 = ds_read_b64_tr_b16 transpose reads. */
+OAKE_API int oake_debug_set_attention_variant(int use_tr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OAKE_HIP_H_ */

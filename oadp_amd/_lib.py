@@ -1,0 +1,84 @@
+"""ctypes binding of liboake_hip.so (include/oake_hip.h).  No CPU fallback: if the HIP library
+is missing or fails to load, importing a model raises — the product path never routes around it."""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+
+OAKE_OK = 0
+OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
+ABI_VERSION = 1
+
+LIB_PATH = pathlib.Path(__file__).resolve().parent / 'liboake_hip.so'
+
+
+class OakeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'image_size', 'patch_size', 'stride', 'padding', 'width', 'layers', 'heads', 'mlp_dim',
+        'embed_dim', 'compute_dtype', 'max_batch', 'reserved')]
+
+
+class ProfileEntry(C.Structure):
+    _fields_ = [('name', C.c_char * 48), ('total_ms', C.c_double), ('flops', C.c_double),
+                ('bytes', C.c_double), ('launches', C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/oake_hip.h declares
+_VP, _I = C.c_void_p, C.c_int
+SIGNATURES = {
+    'oake_abi_version': (C.c_uint32, []),
+    'oake_default_config': (None, [C.POINTER(OakeConfig)]),
+    'oake_create': (_I, [C.POINTER(OakeConfig), _I, C.POINTER(_VP)]),
+    'oake_destroy': (None, [_VP]),
+    'oake_last_error': (C.c_char_p, [_VP]),
+    'oake_grid': (_I, [_VP]),
+    'oake_tokens': (_I, [_VP]),
+    'oake_load_tensor': (_I, [_VP, C.c_char_p, _VP, C.c_size_t]),
+    'oake_missing_tensors': (_I, [_VP]),
+    'oake_encode_image': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
+    'oake_encode_objects': (_I, [_VP, _VP, _I, _VP, _I, _I, _VP, _I, _I, _VP]),
+    'oake_crop_normalize': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, C.POINTER(C.c_float),
+                                 C.POINTER(C.c_float), _VP, _I, _VP]),
+    'oake_profile_enable': (_I, [_VP, _I]),
+    'oake_profile_read': (_I, [_VP, C.POINTER(ProfileEntry), _I, C.POINTER(_I)]),
+    'oake_profile_reset': (_I, [_VP]),
+    'oake_debug_gemm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    'oake_debug_layernorm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
+    'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
+    'oake_debug_set_attention_variant': (_I, [_I]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load liboake_hip.so.  ``import torch`` first so the HIP runtime torch ships (same SONAME,
+    libamdhip64.so.7) is the one the library binds to — one runtime, shared streams/pointers."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's libamdhip64 before ours is resolved)
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f'{LIB_PATH} not found: build it with `python -m oadp_amd.build` '
+            '(or __graft_entry__.build()); there is no CPU fallback')
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_LOCAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oake_abi_version() != ABI_VERSION:
+        raise ImportError(f'liboake_hip.so ABI {lib.oake_abi_version()} != {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+class OakeError(RuntimeError):
+    pass
+
+
+def check(lib: C.CDLL, handle, rc: int, what: str) -> None:
+    if rc != OAKE_OK:
+        msg = lib.oake_last_error(handle)
+        raise OakeError(f'{what} failed (status {rc}): {msg.decode() if msg else "?"}')

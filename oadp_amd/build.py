@@ -1,0 +1,77 @@
+"""Build liboake_hip.so (the C-ABI library of include/oake_hip.h) with hipcc for gfx950.
+
+In-tree build: objects go to ``oadp_amd/csrc/_build/``, the shared library to
+``oadp_amd/liboake_hip.so`` (git-ignored, but shipped to the GPU box by gpurun).
+hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import pathlib
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = pathlib.Path(__file__).resolve().parent
+CSRC = ROOT / 'csrc'
+BUILD = CSRC / '_build'
+LIB = ROOT / 'liboake_hip.so'
+SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip', 'api.hip']
+HEADERS = ['common.h', 'kernels.h', '../../include/oake_hip.h']
+ARCH = 'gfx950'
+FLAGS = [
+    f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
+    '-Wall', '-Wno-unused-function',
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _digest(paths: list[pathlib.Path]) -> str:
+    h = hashlib.sha256()
+    h.update(' '.join(FLAGS).encode())
+    for p in paths:
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def _compile(src: str, force: bool) -> pathlib.Path:
+    s = CSRC / src
+    obj = BUILD / (src + '.o')
+    stamp = BUILD / (src + '.sha')
+    dig = _digest([s] + [CSRC / hd for hd in HEADERS])
+    if not force and obj.exists() and stamp.exists() and stamp.read_text() == dig:
+        return obj
+    cmd = [_hipcc(), *FLAGS, '-c', str(s), '-o', str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    stamp.write_text(dig)
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
+    BUILD.mkdir(parents=True, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    newest = max(o.stat().st_mtime for o in objs)
+    if force or not LIB.exists() or LIB.stat().st_mtime < newest:
+        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', str(LIB), *map(str, objs)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    if verbose:
+        print(f'built {LIB}')
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv, verbose=True)

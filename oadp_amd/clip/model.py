@@ -1,0 +1,274 @@
+"""``clip.model`` facade over liboake_hip.so.
+
+Mirrors the attribute surface the reference touches:
+
+    model, preprocess = clip.load_default(flag)          oadp/oake/globals.py:47
+    model.encode_image(images) -> [N, 512]               oadp/oake/globals.py:57, blocks.py:129
+    model.visual(objects, masks) -> [N, 512]             oadp/oake/objects.py:330
+    model.dtype                                          oadp/oake/objects.py:328
+    visual.grid, visual.patch_size, visual.conv1.stride/.padding,
+    visual.positional_embedding, visual.interpolate_positional_embedding(size)
+                                                         oadp/oake/objects.py:292-301
+
+The forward itself runs in hand-written gfx950 kernels behind the C ABI; tensors must live on
+the GPU.  There is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+from typing import Mapping
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from .preprocess import Preprocess
+
+_TORCH2OAKE = {torch.float32: _lib.OAKE_F32, torch.float16: _lib.OAKE_F16,
+               torch.bfloat16: _lib.OAKE_BF16}
+
+VISION_PREFIX = 'visual.'
+
+
+class Conv1Spec:
+    """Stands in for ``visual.conv1`` (an nn.Conv2d in the reference): the reference's objects-mode
+    surgery assigns ``conv1.stride`` and ``conv1.padding`` (objects.py:298-301)."""
+
+    def __init__(self, patch_size: int) -> None:
+        self.kernel_size = (patch_size, patch_size)
+        self.stride = (patch_size, patch_size)
+        self.padding = (0, 0)
+
+
+def _infer_arch(sd: Mapping[str, torch.Tensor]) -> dict:
+    conv = sd['visual.conv1.weight']
+    width, patch = conv.shape[0], conv.shape[-1]
+    pos = sd['visual.positional_embedding']
+    grid = int(round((pos.shape[0] - 1) ** 0.5))
+    layers = len({k.split('.')[3] for k in sd if k.startswith('visual.transformer.resblocks.')})
+    mlp = sd['visual.transformer.resblocks.0.mlp.c_fc.weight'].shape[0]
+    return dict(image_size=grid * patch, patch_size=patch, width=width, layers=layers,
+                heads=width // 64, mlp_dim=mlp, embed_dim=sd['visual.proj'].shape[1])
+
+
+class VisionTransformer:
+
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], *, compute_dtype=torch.float16,
+                 max_batch: int = 256, device: int | None = None) -> None:
+        sd = {k: v.detach().to('cpu', torch.float32).contiguous()
+              for k, v in state_dict.items() if k.startswith(VISION_PREFIX)}
+        self._sd = sd
+        arch = _infer_arch(sd)
+        self.input_resolution = arch['image_size']
+        self.patch_size = arch['patch_size']
+        self.width = arch['width']
+        self.layers = arch['layers']
+        self.heads = arch['heads']
+        self.mlp_dim = arch['mlp_dim']
+        self.output_dim = arch['embed_dim']
+        self.grid = self.input_resolution // self.patch_size
+        self.conv1 = Conv1Spec(self.patch_size)
+        self.positional_embedding = sd['visual.positional_embedding']
+        self.object_stream = False  # set by objects-mode surgery (replaces the reference's Hooks)
+        self.compute_dtype = compute_dtype
+        self.max_batch = max_batch
+        self.device = device
+        self._lib = _lib.load()
+        self._handle = None
+        self._handle_key = None
+
+    # -- reference surface -----------------------------------------------------------------
+    def interpolate_positional_embedding(self, size: tuple[int, int]) -> torch.Tensor:
+        """[1 + g*g, C] -> [1 + size[0]*size[1], C]: CLS row kept, grid rows resampled bicubically
+        (align_corners=False).  The fork's own mode is unknown."""
+        pos = self.positional_embedding.float()
+        g = int(round((pos.shape[0] - 1) ** 0.5))
+        cls, grid = pos[:1], pos[1:].reshape(1, g, g, -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=size, mode='bicubic', align_corners=False)
+        grid = grid.permute(0, 2, 3, 1).reshape(size[0] * size[1], -1)
+        return torch.cat([cls, grid])
+
+    def __call__(self, x: torch.Tensor, masks: torch.Tensor | None = None, *,
+                 normalize: bool = False, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+        if masks is None:
+            if self.object_stream:
+                raise ValueError('objects-mode model: call visual(objects, masks)')
+            return self._forward(x, None, normalize, out_dtype)
+        if not self.object_stream:
+            raise ValueError('visual(x, masks) needs the objects-mode surgery '
+                             '(oadp_amd.oake.objects.Validator._build_model)')
+        return self._forward(x, masks, normalize, out_dtype)
+
+    forward = __call__
+
+    # -- native handle ---------------------------------------------------------------------
+    def _geometry(self) -> tuple[int, int]:
+        stride = self.conv1.stride[0] if isinstance(self.conv1.stride, (tuple, list)) else self.conv1.stride
+        pad = self.conv1.padding[0] if isinstance(self.conv1.padding, (tuple, list)) else self.conv1.padding
+        return int(stride), int(pad)
+
+    def _ensure_handle(self, device_index: int):
+        stride, pad = self._geometry()
+        pos = self.positional_embedding
+        pos = pos.data if isinstance(pos, torch.nn.Parameter) else pos
+        key = (device_index, stride, pad, pos.data_ptr(), tuple(pos.shape), self.compute_dtype,
+               self.max_batch)
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self.close()
+        lib = self._lib
+        cfg = _lib.OakeConfig()
+        lib.oake_default_config(C.byref(cfg))
+        cfg.image_size, cfg.patch_size = self.input_resolution, self.patch_size
+        cfg.stride, cfg.padding = stride, pad
+        cfg.width, cfg.layers, cfg.heads = self.width, self.layers, self.heads
+        cfg.mlp_dim, cfg.embed_dim = self.mlp_dim, self.output_dim
+        cfg.compute_dtype = _TORCH2OAKE[self.compute_dtype]
+        cfg.max_batch = self.max_batch
+        h = C.c_void_p()
+        _lib.check(lib, None, lib.oake_create(C.byref(cfg), device_index, C.byref(h)), 'oake_create')
+        try:
+            tokens = lib.oake_tokens(h)
+            if pos.shape[0] != tokens:
+                raise ValueError(f'positional_embedding has {pos.shape[0]} rows, geometry needs {tokens}')
+            for name, t in self._sd.items():
+                if name == 'visual.positional_embedding':
+                    t = pos.detach().to('cpu', torch.float32).contiguous()
+                _lib.check(lib, h, lib.oake_load_tensor(h, name.encode(), t.data_ptr(), t.numel()),
+                           f'oake_load_tensor({name})')
+            missing = lib.oake_missing_tensors(h)
+            if missing:
+                raise ValueError(f'state_dict lacks {missing} vision-tower tensors')
+        except Exception:
+            lib.oake_destroy(h)
+            raise
+        self._handle, self._handle_key = h, key
+        return h
+
+    def close(self) -> None:
+        if self._handle is not None:
+            self._lib.oake_destroy(self._handle)
+            self._handle = None
+            self._handle_key = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _forward(self, x, masks, normalize, out_dtype) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError('oadp_amd.clip runs on the GPU only (no CPU fallback): move the '
+                               'input to a HIP device')
+        if x.dtype not in _TORCH2OAKE:
+            raise TypeError(f'unsupported input dtype {x.dtype}')
+        s = self.input_resolution
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, s, s):
+            raise ValueError(f'expected [N,3,{s},{s}], got {tuple(x.shape)}')
+        out_dtype = out_dtype or self.compute_dtype
+        if out_dtype == torch.bfloat16:
+            raw_dtype = torch.float32
+        elif out_dtype in (torch.float32, torch.float16):
+            raw_dtype = out_dtype
+        else:
+            raise TypeError(f'unsupported output dtype {out_dtype}')
+        dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        x = x.contiguous()
+        n = x.shape[0]
+        out = torch.empty((n, self.output_dim), dtype=raw_dtype, device=x.device)
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            lib = self._lib
+            if masks is None:
+                rc = lib.oake_encode_image(h, x.data_ptr(), _TORCH2OAKE[x.dtype], n, out.data_ptr(),
+                                           _TORCH2OAKE[raw_dtype], int(normalize), stream)
+                _lib.check(lib, h, rc, 'oake_encode_image')
+            else:
+                g = lib.oake_grid(h)
+                if masks.dtype not in (torch.float32, torch.float16):
+                    masks = masks.float()
+                if masks.shape[0] != n or masks.numel() != n * g * g:
+                    raise ValueError(f'masks must be [N,1,{g},{g}], got {tuple(masks.shape)}')
+                masks = masks.to(x.device).contiguous()
+                rc = lib.oake_encode_objects(h, x.data_ptr(), _TORCH2OAKE[x.dtype], masks.data_ptr(),
+                                             _TORCH2OAKE[masks.dtype], n, out.data_ptr(),
+                                             _TORCH2OAKE[raw_dtype], int(normalize), stream)
+                _lib.check(lib, h, rc, 'oake_encode_objects')
+        return out if out.dtype == out_dtype else out.to(out_dtype)
+
+    # -- profiler (bench.py) ---------------------------------------------------------------
+    def profile(self, enable: bool) -> None:
+        if self._handle is None:
+            raise RuntimeError('run one forward before enabling the profiler')
+        self._lib.oake_profile_reset(self._handle)
+        self._lib.oake_profile_enable(self._handle, int(enable))
+
+    def profile_read(self) -> list[dict]:
+        n = C.c_int(0)
+        buf = (_lib.ProfileEntry * 64)()
+        _lib.check(self._lib, self._handle,
+                   self._lib.oake_profile_read(self._handle, buf, 64, C.byref(n)), 'profile_read')
+        return [dict(name=buf[i].name.decode(), total_ms=buf[i].total_ms, flops=buf[i].flops,
+                     bytes=buf[i].bytes, launches=buf[i].launches) for i in range(min(n.value, 64))]
+
+
+class CLIP:
+    """The vision half of ``clip.model.CLIP`` (OAKE never calls the text tower)."""
+
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], **kwargs) -> None:
+        self.visual = VisionTransformer(state_dict, **kwargs)
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.visual.compute_dtype
+
+    def encode_image(self, image: torch.Tensor, **kwargs) -> torch.Tensor:
+        # reference: self.visual(image.type(self.dtype)); the cast happens inside the im2col kernel
+        return self.visual(image, **kwargs)
+
+    def eval(self) -> 'CLIP':
+        return self
+
+    def requires_grad_(self, flag: bool = False) -> 'CLIP':
+        return self
+
+
+DEFAULT_CHECKPOINT = 'pretrained/clip/ViT-B-32.pt'  # reference README.md:129
+
+
+def _read_checkpoint(path: str | os.PathLike) -> dict[str, torch.Tensor]:
+    p = pathlib.Path(path)
+    try:  # OpenAI checkpoints are TorchScript archives
+        return dict(torch.jit.load(str(p), map_location='cpu').state_dict())
+    except RuntimeError:
+        obj = torch.load(str(p), map_location='cpu')
+        return dict(obj.get('state_dict', obj))
+
+
+def load(state_dict: Mapping[str, torch.Tensor] | str | os.PathLike, *, squash: bool = False,
+         **kwargs) -> tuple[CLIP, Preprocess]:
+    if not isinstance(state_dict, Mapping):
+        state_dict = _read_checkpoint(state_dict)
+    model = CLIP(state_dict, **kwargs)
+    return model, Preprocess(model.visual.input_resolution, squash=squash)
+
+
+def load_default(flag: bool = False, **kwargs) -> tuple[CLIP, Preprocess]:
+    """``clip.load_default(flag)`` of the fork: ViT-B/32 + its transform.  ``flag`` selects the
+    transform variant (see Preprocess).  Weights: ``$OAKE_CLIP_CHECKPOINT`` or
+    pretrained/clip/ViT-B-32.pt; with ``OAKE_SYNTHETIC_WEIGHTS=1`` (or DRY_RUN=True and no
+    checkpoint on disk) the deterministic synthetic ViT-B/32 of oadp_amd.weights is used."""
+    path = os.environ.get('OAKE_CLIP_CHECKPOINT', DEFAULT_CHECKPOINT)
+    synthetic = os.environ.get('OAKE_SYNTHETIC_WEIGHTS', '') not in ('', '0', 'False')
+    dry = os.environ.get('DRY_RUN', '') not in ('', '0', 'False')
+    if not synthetic and os.path.exists(path):
+        return load(path, squash=flag, **kwargs)
+    if synthetic or dry:
+        from ..weights import synthetic_state_dict
+        return load(synthetic_state_dict(), squash=flag, **kwargs)
+    raise FileNotFoundError(f'{path} not found (set OAKE_CLIP_CHECKPOINT, or '
+                            'OAKE_SYNTHETIC_WEIGHTS=1 for random-init weights)')

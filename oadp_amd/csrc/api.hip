@@ -1,0 +1,664 @@
+// api.hip — the extern "C" surface of liboake_hip.so (include/oake_hip.h): handle lifetime, weight
+// upload in the OpenAI-CLIP state_dict layout, the encode_image / objects-mode schedules, and the
+// per-kernel HIP-event profiler that bench.py's `roofline` object reads.
+//
+// Schedules (reference call sites cited in include/oake_hip.h):
+//   encode_image : im2col -> conv1 GEMM(+pos) -> cls+ln_pre -> 12 x { ln_1 -> QKV GEMM -> attention
+//                  -> out_proj GEMM(+residual) -> ln_2 -> c_fc GEMM(+QuickGELU) -> c_proj
+//                  GEMM(+residual) } -> ln_post/proj/L2-normalise head
+//   objects mode : same patch/token pipeline at stride 16 (197 tokens) plus the reference Hooks'
+//                  object-token stream y; the two exact savings of SURVEY.md Appendix C are taken:
+//                  patch-row K/V are projected once per layer and shared by both streams, and the
+//                  last layer's main stream (never read) is not executed.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/oake_hip.h"
+#include "kernels.h"
+
+namespace oake {
+extern int g_attention_use_tr;
+}
+
+using namespace oake;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct LayerW {
+  float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  void *in_w = nullptr, *out_w = nullptr, *fc_w = nullptr, *proj_w = nullptr;  // 16-bit [N,K]
+  float *in_b = nullptr, *out_b = nullptr, *fc_b = nullptr, *proj_b = nullptr;
+};
+
+struct ProfSlot {
+  std::string name;
+  double flops = 0, bytes = 0;
+  int64_t launches = 0;
+  double ms = 0;
+};
+
+struct PendingEvt {
+  int slot;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct oake_handle {
+  oake_config cfg{};
+  int device = 0;
+  int grid = 0, tokens = 0, p2 = 0, kpatch = 0;
+  int dt16 = DT_F16;
+  std::string err;
+
+  // weights
+  void* conv_w = nullptr;     // [width, 3*P*P] 16-bit
+  float* cls = nullptr;       // [width]
+  float* pos = nullptr;       // [tokens, width]
+  float *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr;
+  void* proj = nullptr;       // [width, embed] 16-bit
+  std::vector<LayerW> layers;
+  std::map<std::string, bool> loaded;
+  float* stage = nullptr;     // fp32 staging for uploads
+  size_t stage_elems = 0;
+
+  // workspace (sized for cfg.max_batch crops)
+  void* a_patch = nullptr;
+  float* x = nullptr;
+  void *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr;
+  float* y = nullptr;
+  void *yn = nullptr, *qkv_y = nullptr, *att_y = nullptr, *h_y = nullptr;
+
+  // profiler
+  bool prof = false;
+  std::vector<ProfSlot> slots;
+  std::vector<PendingEvt> pending;
+  std::vector<hipEvent_t> evt_pool;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                      \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+      return OAKE_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+
+size_t e16() { return 2; }
+
+int fail(oake_handle* h, int code, const std::string& msg) {
+  h->err = msg;
+  return code;
+}
+
+int slot_of(oake_handle* h, const char* name) {
+  for (size_t i = 0; i < h->slots.size(); ++i)
+    if (h->slots[i].name == name) return (int)i;
+  ProfSlot s;
+  s.name = name;
+  h->slots.push_back(s);
+  return (int)h->slots.size() - 1;
+}
+
+hipEvent_t get_evt(oake_handle* h) {
+  if (!h->evt_pool.empty()) {
+    hipEvent_t e = h->evt_pool.back();
+    h->evt_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+// RAII-less bracket: begin returns the index into pending (or -1 when profiling is off)
+int prof_begin(oake_handle* h, const char* name, double flops, double bytes, hipStream_t s) {
+  if (!h->prof) return -1;
+  const int sl = slot_of(h, name);
+  h->slots[sl].flops += flops;
+  h->slots[sl].bytes += bytes;
+  h->slots[sl].launches += 1;
+  PendingEvt p{sl, get_evt(h), get_evt(h)};
+  (void)hipEventRecord(p.a, s);
+  h->pending.push_back(p);
+  return (int)h->pending.size() - 1;
+}
+void prof_end(oake_handle* h, int idx, hipStream_t s) {
+  if (idx >= 0) (void)hipEventRecord(h->pending[idx].b, s);
+}
+
+void prof_collect(oake_handle* h) {
+  for (auto& p : h->pending) {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->slots[p.slot].ms += ms;
+    h->evt_pool.push_back(p.a);
+    h->evt_pool.push_back(p.b);
+  }
+  h->pending.clear();
+}
+
+#define RUN(h, s, name, flops, bytes, call)                 \
+  do {                                                      \
+    const int _pi = prof_begin(h, name, flops, bytes, s);   \
+    hipError_t _e = (call);                                 \
+    prof_end(h, _pi, s);                                    \
+    if (_e != hipSuccess) {                                 \
+      (h)->err = std::string(name) + ": " + hipGetErrorString(_e); \
+      return OAKE_ERR_HIP;                                  \
+    }                                                       \
+  } while (0)
+
+int alloc(oake_handle* h, void** p, size_t bytes) {
+  HIP_TRY(h, hipMalloc(p, bytes ? bytes : 16));
+  return OAKE_OK;
+}
+
+const char* kGlobalNames[] = {"visual.conv1.weight",   "visual.class_embedding",
+                              "visual.positional_embedding", "visual.ln_pre.weight",
+                              "visual.ln_pre.bias",    "visual.ln_post.weight",
+                              "visual.ln_post.bias",   "visual.proj"};
+const char* kLayerNames[] = {"ln_1.weight",          "ln_1.bias",         "ln_2.weight",
+                             "ln_2.bias",            "attn.in_proj_weight", "attn.in_proj_bias",
+                             "attn.out_proj.weight", "attn.out_proj.bias", "mlp.c_fc.weight",
+                             "mlp.c_fc.bias",        "mlp.c_proj.weight", "mlp.c_proj.bias"};
+
+std::string layer_key(int l, const char* leaf) {
+  return "visual.transformer.resblocks." + std::to_string(l) + "." + leaf;
+}
+
+int upload_f32(oake_handle* h, float* dst, const float* src, size_t numel) {
+  HIP_TRY(h, hipMemcpy(dst, src, numel * sizeof(float), hipMemcpyHostToDevice));
+  return OAKE_OK;
+}
+
+int upload_16(oake_handle* h, void* dst, const float* src, size_t numel) {
+  if (numel > h->stage_elems) return fail(h, OAKE_ERR_INVALID, "staging buffer too small");
+  HIP_TRY(h, hipMemcpy(h->stage, src, numel * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(h, launch_cast_f32_to_16(h->dt16, h->stage, dst, numel, 1.0f, 0));
+  HIP_TRY(h, hipStreamSynchronize(0));
+  return OAKE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t oake_abi_version(void) { return OAKE_ABI_VERSION; }
+
+void oake_default_config(oake_config* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->image_size = 224;
+  c->patch_size = 32;
+  c->stride = 32;
+  c->padding = 0;
+  c->width = 768;
+  c->layers = 12;
+  c->heads = 12;
+  c->mlp_dim = 3072;
+  c->embed_dim = 512;
+  c->compute_dtype = OAKE_F16;
+  c->max_batch = 256;
+}
+
+const char* oake_last_error(const oake_handle* h) {
+  return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+int oake_grid(const oake_handle* h) { return h ? h->grid : 0; }
+int oake_tokens(const oake_handle* h) { return h ? h->tokens : 0; }
+
+void oake_destroy(oake_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
+                  h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y,
+                  h->yn, h->qkv_y, h->att_y, h->h_y};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& l : h->layers) {
+    void* lp[] = {l.ln1_g, l.ln1_b, l.ln2_g, l.ln2_b, l.in_w, l.out_w, l.fc_w, l.proj_w,
+                  l.in_b, l.out_b, l.fc_b, l.proj_b};
+    for (void* p : lp)
+      if (p) (void)hipFree(p);
+  }
+  prof_collect(h);
+  for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+  delete h;
+}
+
+int oake_create(const oake_config* cfg, int device, oake_handle** out) {
+  if (!cfg || !out) {
+    g_create_error = "null argument";
+    return OAKE_ERR_INVALID;
+  }
+  *out = nullptr;
+  const oake_config& c = *cfg;
+  auto bad = [&](const char* m) {
+    g_create_error = m;
+    return OAKE_ERR_INVALID;
+  };
+  if (c.width <= 0 || c.heads <= 0 || c.width != c.heads * 64)
+    return bad("width must equal heads * 64 (head_dim 64)");
+  if (c.width % 64 != 0 || c.mlp_dim % 64 != 0 || c.width > 1024)
+    return bad("width/mlp_dim must be multiples of 64 and width <= 1024");
+  if (c.patch_size % 8 != 0 || (3 * c.patch_size * c.patch_size) % 64 != 0)
+    return bad("patch_size must be a multiple of 8");
+  if (c.stride <= 0 || c.padding < 0 || c.image_size + 2 * c.padding < c.patch_size)
+    return bad("bad conv1 geometry");
+  if (c.embed_dim % 2 != 0 || c.embed_dim > 1024 || c.embed_dim <= 0) return bad("bad embed_dim");
+  if (c.compute_dtype != OAKE_F16 && c.compute_dtype != OAKE_BF16)
+    return bad("compute_dtype must be OAKE_F16 or OAKE_BF16");
+  if (c.layers <= 0 || c.max_batch <= 0) return bad("layers and max_batch must be positive");
+
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return OAKE_ERR_HIP;
+  }
+  oake_handle* h = new oake_handle();
+  h->cfg = c;
+  h->device = device;
+  h->dt16 = c.compute_dtype;
+  h->grid = (c.image_size + 2 * c.padding - c.patch_size) / c.stride + 1;
+  h->p2 = h->grid * h->grid;
+  h->tokens = h->p2 + 1;
+  h->kpatch = 3 * c.patch_size * c.patch_size;
+  h->layers.resize(c.layers);
+
+  const size_t C = c.width, F = c.mlp_dim, E = c.embed_dim, L = h->tokens, B = c.max_batch;
+  int rc = OAKE_OK;
+  auto A = [&](void** p, size_t bytes) {
+    if (rc == OAKE_OK) rc = alloc(h, p, bytes);
+  };
+  A(&h->conv_w, C * h->kpatch * e16());
+  A((void**)&h->cls, C * 4);
+  A((void**)&h->pos, L * C * 4);
+  A((void**)&h->lnpre_g, C * 4);
+  A((void**)&h->lnpre_b, C * 4);
+  A((void**)&h->lnpost_g, C * 4);
+  A((void**)&h->lnpost_b, C * 4);
+  A(&h->proj, C * E * e16());
+  for (auto& l : h->layers) {
+    A((void**)&l.ln1_g, C * 4);
+    A((void**)&l.ln1_b, C * 4);
+    A((void**)&l.ln2_g, C * 4);
+    A((void**)&l.ln2_b, C * 4);
+    A(&l.in_w, 3 * C * C * e16());
+    A(&l.out_w, C * C * e16());
+    A(&l.fc_w, F * C * e16());
+    A(&l.proj_w, C * F * e16());
+    A((void**)&l.in_b, 3 * C * 4);
+    A((void**)&l.out_b, C * 4);
+    A((void**)&l.fc_b, F * 4);
+    A((void**)&l.proj_b, C * 4);
+  }
+  h->stage_elems = std::max<size_t>(std::max<size_t>(C * h->kpatch, F * C), std::max<size_t>(3 * C * C, L * C));
+  A((void**)&h->stage, h->stage_elems * 4);
+  // workspace
+  A(&h->a_patch, B * h->p2 * h->kpatch * e16());
+  A((void**)&h->x, B * L * C * 4);
+  A(&h->xn, B * L * C * e16());
+  A(&h->qkv, B * L * 3 * C * e16());
+  A(&h->att, B * L * C * e16());
+  A(&h->hbuf, B * L * F * e16());
+  A((void**)&h->y, B * C * 4);
+  A(&h->yn, B * C * e16());
+  A(&h->qkv_y, B * 3 * C * e16());
+  A(&h->att_y, B * C * e16());
+  A(&h->h_y, B * F * e16());
+  if (rc != OAKE_OK) {
+    g_create_error = h->err;
+    oake_destroy(h);
+    return rc;
+  }
+  for (const char* n : kGlobalNames) h->loaded[n] = false;
+  for (int l = 0; l < c.layers; ++l)
+    for (const char* n : kLayerNames) h->loaded[layer_key(l, n)] = false;
+  *out = h;
+  return OAKE_OK;
+}
+
+int oake_missing_tensors(const oake_handle* h) {
+  if (!h) return -1;
+  int m = 0;
+  for (auto& kv : h->loaded) m += kv.second ? 0 : 1;
+  return m;
+}
+
+int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t numel) {
+  if (!h || !name || !data) return OAKE_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const std::string key(name);
+  auto it = h->loaded.find(key);
+  if (it == h->loaded.end()) return fail(h, OAKE_ERR_UNKNOWN_TENSOR, "unknown tensor: " + key);
+  const size_t C = h->cfg.width, F = h->cfg.mlp_dim, E = h->cfg.embed_dim, L = h->tokens;
+  auto expect = [&](size_t n) -> int {
+    if (numel != n)
+      return fail(h, OAKE_ERR_INVALID,
+                  key + ": expected " + std::to_string(n) + " elements, got " + std::to_string(numel));
+    return OAKE_OK;
+  };
+  int rc = OAKE_OK;
+#define F32(dst, n)                                   \
+  do {                                                \
+    if ((rc = expect(n)) != OAKE_OK) return rc;       \
+    if ((rc = upload_f32(h, dst, data, n)) != OAKE_OK) return rc; \
+  } while (0)
+#define W16(dst, n)                                   \
+  do {                                                \
+    if ((rc = expect(n)) != OAKE_OK) return rc;       \
+    if ((rc = upload_16(h, dst, data, n)) != OAKE_OK) return rc;  \
+  } while (0)
+
+  if (key == "visual.conv1.weight") W16(h->conv_w, C * h->kpatch);
+  else if (key == "visual.class_embedding") F32(h->cls, C);
+  else if (key == "visual.positional_embedding") F32(h->pos, L * C);
+  else if (key == "visual.ln_pre.weight") F32(h->lnpre_g, C);
+  else if (key == "visual.ln_pre.bias") F32(h->lnpre_b, C);
+  else if (key == "visual.ln_post.weight") F32(h->lnpost_g, C);
+  else if (key == "visual.ln_post.bias") F32(h->lnpost_b, C);
+  else if (key == "visual.proj") W16(h->proj, C * E);
+  else {
+    // visual.transformer.resblocks.<l>.<leaf>
+    const std::string prefix = "visual.transformer.resblocks.";
+    const size_t dot = key.find('.', prefix.size());
+    const int l = std::stoi(key.substr(prefix.size(), dot - prefix.size()));
+    const std::string leaf = key.substr(dot + 1);
+    LayerW& w = h->layers[l];
+    if (leaf == "ln_1.weight") F32(w.ln1_g, C);
+    else if (leaf == "ln_1.bias") F32(w.ln1_b, C);
+    else if (leaf == "ln_2.weight") F32(w.ln2_g, C);
+    else if (leaf == "ln_2.bias") F32(w.ln2_b, C);
+    else if (leaf == "attn.in_proj_weight") {
+      // fold the attention scale head_dim^-0.5 = 1/8 (exact in binary) into the q rows
+      if ((rc = expect(3 * C * C)) != OAKE_OK) return rc;
+      HIP_TRY(h, hipMemcpy(h->stage, data, numel * 4, hipMemcpyHostToDevice));
+      HIP_TRY(h, launch_scale_f32(h->stage, C * C, 0.125f, 0));
+      HIP_TRY(h, launch_cast_f32_to_16(h->dt16, h->stage, w.in_w, numel, 1.0f, 0));
+      HIP_TRY(h, hipStreamSynchronize(0));
+    } else if (leaf == "attn.in_proj_bias") {
+      F32(w.in_b, 3 * C);
+      HIP_TRY(h, launch_scale_f32(w.in_b, C, 0.125f, 0));
+      HIP_TRY(h, hipStreamSynchronize(0));
+    } else if (leaf == "attn.out_proj.weight") W16(w.out_w, C * C);
+    else if (leaf == "attn.out_proj.bias") F32(w.out_b, C);
+    else if (leaf == "mlp.c_fc.weight") W16(w.fc_w, F * C);
+    else if (leaf == "mlp.c_fc.bias") F32(w.fc_b, F);
+    else if (leaf == "mlp.c_proj.weight") W16(w.proj_w, C * F);
+    else if (leaf == "mlp.c_proj.bias") F32(w.proj_b, C);
+    else return fail(h, OAKE_ERR_UNKNOWN_TENSOR, "unknown tensor: " + key);
+  }
+#undef F32
+#undef W16
+  it->second = true;
+  return OAKE_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// ---- shared pieces of the two schedules -------------------------------------------------------
+int gemm(oake_handle* h, hipStream_t s, const char* name, int epi, const void* A, const void* W,
+         const float* bias, void* out, int M, int N, int K, int ldo) {
+  GemmArgs a{};
+  a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
+  RUN(h, s, name, 2.0 * M * N * K, 0.0, launch_gemm(h->dt16, epi, a, s));
+  return OAKE_OK;
+}
+
+int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, int nb) {
+  const oake_config& c = h->cfg;
+  const int C = c.width, L = h->tokens;
+  const size_t in_es = in_dtype == DT_F32 ? 4 : 2;
+  const double im_bytes = (double)nb * h->p2 * h->kpatch * 2 + (double)nb * 3 * c.image_size * c.image_size * in_es;
+  RUN(h, s, "im2col", 0.0, im_bytes,
+      launch_im2col(h->dt16, imgs, in_dtype, h->a_patch, nb, c.image_size, c.patch_size, c.stride,
+                    c.padding, h->grid, s));
+  GemmArgs a{};
+  a.A = h->a_patch; a.W = h->conv_w; a.bias = nullptr; a.out = h->x;
+  a.M = nb * h->p2; a.N = C; a.K = h->kpatch; a.ldo = C; a.pos = h->pos; a.P2 = h->p2; a.L = L;
+  RUN(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0, launch_gemm(h->dt16, EPI_PATCH, a, s));
+  RUN(h, s, "embed_ln_pre", 0.0, 2.0 * nb * L * C * 4,
+      launch_embed_ln_pre(h->x, h->cls, h->pos, h->lnpre_g, h->lnpre_b, nb, L, C, s));
+  return OAKE_OK;
+}
+
+int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
+  // attention + out_proj + MLP of the main token stream (qkv already computed)
+  const int C = h->cfg.width, F = h->cfg.mlp_dim, L = h->tokens, T = nb * L;
+  const int Lp = ((L + 63) / 64) * 64;
+  RUN(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
+      launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, s));
+  int rc;
+  if ((rc = gemm(h, s, "gemm_out_proj", EPI_RESID, h->att, w.out_w, w.out_b, h->x, T, C, C, C))) return rc;
+  RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
+      launch_layernorm(h->dt16, h->x, C, w.ln2_g, w.ln2_b, h->xn, T, C, s));
+  if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU, h->xn, w.fc_w, w.fc_b, h->hbuf, T, F, C, F))) return rc;
+  if ((rc = gemm(h, s, "gemm_c_proj", EPI_RESID, h->hbuf, w.proj_w, w.proj_b, h->x, T, C, F, C))) return rc;
+  return OAKE_OK;
+}
+
+int check_ready(oake_handle* h) {
+  const int m = oake_missing_tensors(h);
+  if (m != 0) return fail(h, OAKE_ERR_STATE, std::to_string(m) + " weight tensors not loaded");
+  return OAKE_OK;
+}
+
+size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : (dt == DT_U8 ? 1 : 2); }
+
+}  // namespace
+
+extern "C" {
+
+int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n, void* d_out,
+                      int out_dtype, int normalize, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (n < 0) return fail(h, OAKE_ERR_INVALID, "negative batch");
+  if (n == 0) return OAKE_OK;
+  if (!d_images || !d_out) return fail(h, OAKE_ERR_INVALID, "null device pointer");
+  if (in_dtype != OAKE_F32 && in_dtype != OAKE_F16 && in_dtype != OAKE_BF16)
+    return fail(h, OAKE_ERR_INVALID, "in_dtype must be F32, F16 or BF16");
+  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  int rc = check_ready(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const oake_config& c = h->cfg;
+  const int C = c.width, L = h->tokens;
+  const size_t img_bytes = (size_t)3 * c.image_size * c.image_size * dtype_size(in_dtype);
+  const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
+
+  for (int b0 = 0; b0 < n; b0 += c.max_batch) {
+    const int nb = std::min(c.max_batch, n - b0);
+    const int T = nb * L;
+    const char* imgs = reinterpret_cast<const char*>(d_images) + (size_t)b0 * img_bytes;
+    char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
+    if ((rc = patch_embed(h, s, imgs, in_dtype, nb))) return rc;
+    for (int l = 0; l < c.layers; ++l) {
+      const LayerW& w = h->layers[l];
+      RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
+          launch_layernorm(h->dt16, h->x, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
+      if ((rc = gemm(h, s, "gemm_qkv", EPI_T16_BIAS, h->xn, w.in_w, w.in_b, h->qkv, T, 3 * C, C, 3 * C)))
+        return rc;
+      if ((rc = main_block_tail(h, s, w, nb))) return rc;
+    }
+    RUN(h, s, "head", 2.0 * nb * C * c.embed_dim, 0.0,
+        launch_head(h->dt16, h->x, (long)L * C, h->lnpost_g, h->lnpost_b, h->proj, outp, out_dtype,
+                    normalize, nb, C, c.embed_dim, s));
+  }
+  return OAKE_OK;
+}
+
+int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, const void* d_masks,
+                        int mask_dtype, int n, void* d_out, int out_dtype, int normalize,
+                        void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (n < 0) return fail(h, OAKE_ERR_INVALID, "negative batch");
+  if (n == 0) return OAKE_OK;
+  if (!d_objects || !d_masks || !d_out) return fail(h, OAKE_ERR_INVALID, "null device pointer");
+  if (in_dtype != OAKE_F32 && in_dtype != OAKE_F16 && in_dtype != OAKE_BF16)
+    return fail(h, OAKE_ERR_INVALID, "in_dtype must be F32, F16 or BF16");
+  if (mask_dtype != OAKE_F32 && mask_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "mask_dtype must be F32 or F16");
+  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  int rc = check_ready(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const oake_config& c = h->cfg;
+  const int C = c.width, F = c.mlp_dim, L = h->tokens;
+  const size_t img_bytes = (size_t)3 * c.image_size * c.image_size * dtype_size(in_dtype);
+  const size_t mask_bytes = (size_t)h->p2 * dtype_size(mask_dtype);
+  const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
+
+  for (int b0 = 0; b0 < n; b0 += c.max_batch) {
+    const int nb = std::min(c.max_batch, n - b0);
+    const int T = nb * L;
+    const char* imgs = reinterpret_cast<const char*>(d_objects) + (size_t)b0 * img_bytes;
+    const char* masks = reinterpret_cast<const char*>(d_masks) + (size_t)b0 * mask_bytes;
+    char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
+    if ((rc = patch_embed(h, s, imgs, in_dtype, nb))) return rc;
+    // Hooks.transformer_forward_pre (objects.py:215-221): y = x[[0]] (after ln_pre)
+    RUN(h, s, "copy_cls", 0.0, 2.0 * nb * C * 4, launch_copy_cls(h->x, h->y, nb, L, C, s));
+    for (int l = 0; l < c.layers; ++l) {
+      const LayerW& w = h->layers[l];
+      const bool last = (l == c.layers - 1);
+      // ln_1 + in-proj of the main stream: k/v of patch rows serve both streams (Appendix C #1)
+      RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
+          launch_layernorm(h->dt16, h->x, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
+      if (!last) {
+        if ((rc = gemm(h, s, "gemm_qkv", EPI_T16_BIAS, h->xn, w.in_w, w.in_b, h->qkv, T, 3 * C, C, 3 * C)))
+          return rc;
+      } else {
+        // last layer: the main stream's q is dead (Appendix C #2) — project k and v only
+        const char* wkv = reinterpret_cast<const char*>(w.in_w) + (size_t)C * C * 2;
+        char* okv = reinterpret_cast<char*>(h->qkv) + (size_t)C * 2;
+        if ((rc = gemm(h, s, "gemm_kv", EPI_T16_BIAS, h->xn, wkv, w.in_b + C, okv, T, 2 * C, C, 3 * C)))
+          return rc;
+      }
+      // object-token stream (Hooks.residual_attention_block_forward_pre, objects.py:223-247)
+      RUN(h, s, "layernorm_y", 0.0, (double)nb * C * 6,
+          launch_layernorm(h->dt16, h->y, C, w.ln1_g, w.ln1_b, h->yn, nb, C, s));
+      if ((rc = gemm(h, s, "gemm_qkv_y", EPI_T16_BIAS, h->yn, w.in_w, w.in_b, h->qkv_y, nb, 3 * C, C, 3 * C)))
+        return rc;
+      RUN(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
+          launch_object_attention(h->dt16, h->qkv, h->qkv_y, masks, mask_dtype, h->att_y, nb, L,
+                                  c.heads, s));
+      if ((rc = gemm(h, s, "gemm_out_proj_y", EPI_RESID, h->att_y, w.out_w, w.out_b, h->y, nb, C, C, C)))
+        return rc;
+      RUN(h, s, "layernorm_y", 0.0, (double)nb * C * 6,
+          launch_layernorm(h->dt16, h->y, C, w.ln2_g, w.ln2_b, h->yn, nb, C, s));
+      if ((rc = gemm(h, s, "gemm_c_fc_y", EPI_T16_GELU, h->yn, w.fc_w, w.fc_b, h->h_y, nb, F, C, F)))
+        return rc;
+      if ((rc = gemm(h, s, "gemm_c_proj_y", EPI_RESID, h->h_y, w.proj_w, w.proj_b, h->y, nb, C, F, C)))
+        return rc;
+      // main stream forward of this block (skipped for the last block: its output is replaced by
+      // y in Hooks.transformer_forward, objects.py:249-258)
+      if (!last && (rc = main_block_tail(h, s, w, nb))) return rc;
+    }
+    RUN(h, s, "head", 2.0 * nb * C * c.embed_dim, 0.0,
+        launch_head(h->dt16, h->y, (long)C, h->lnpost_g, h->lnpost_b, h->proj, outp, out_dtype,
+                    normalize, nb, C, c.embed_dim, s));
+  }
+  return OAKE_OK;
+}
+
+int oake_crop_normalize(oake_handle* h, const uint8_t* d_image_hwc, int height, int width,
+                        const int32_t* d_boxes_xyxy, int k, int out_size, const float* h_mean3,
+                        const float* h_std3, void* d_out, int out_dtype, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (k < 0 || height <= 0 || width <= 0 || out_size <= 0)
+    return fail(h, OAKE_ERR_INVALID, "bad crop geometry");
+  if (k == 0) return OAKE_OK;
+  if (!d_image_hwc || !d_boxes_xyxy || !d_out || !h_mean3 || !h_std3)
+    return fail(h, OAKE_ERR_INVALID, "null pointer");
+  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const double bytes = (double)k * out_size * out_size * 3 * (1 + dtype_size(out_dtype));
+  RUN(h, s, "crop_normalize", 0.0, bytes,
+      launch_crop_normalize(d_image_hwc, height, width, d_boxes_xyxy, k, out_size, h_mean3, h_std3,
+                            d_out, out_dtype, s));
+  return OAKE_OK;
+}
+
+int oake_profile_enable(oake_handle* h, int enable) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (!enable) prof_collect(h);
+  h->prof = enable != 0;
+  return OAKE_OK;
+}
+
+int oake_profile_reset(oake_handle* h) {
+  if (!h) return OAKE_ERR_INVALID;
+  prof_collect(h);
+  h->slots.clear();
+  return OAKE_OK;
+}
+
+int oake_profile_read(oake_handle* h, oake_profile_entry* entries, int cap, int* count) {
+  if (!h || !count) return OAKE_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  prof_collect(h);
+  const int n = (int)h->slots.size();
+  *count = n;
+  for (int i = 0; i < n && i < cap && entries; ++i) {
+    std::memset(&entries[i], 0, sizeof(entries[i]));
+    std::snprintf(entries[i].name, sizeof(entries[i].name), "%s", h->slots[i].name.c_str());
+    entries[i].total_ms = h->slots[i].ms;
+    entries[i].flops = h->slots[i].flops;
+    entries[i].bytes = h->slots[i].bytes;
+    entries[i].launches = h->slots[i].launches;
+  }
+  return OAKE_OK;
+}
+
+// ---- kernel-level test entry points -----------------------------------------------------------
+static int dbg(hipError_t e) { return e == hipSuccess ? OAKE_OK : OAKE_ERR_HIP; }
+
+int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bias, float* d_c, int m, int n,
+                    int k, int dtype16, void* stream) {
+  GemmArgs a{};
+  a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
+  return dbg(launch_gemm(dtype16, EPI_F32_BIAS, a, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, void* d_y,
+                         int rows, int c, int dtype16, void* stream) {
+  return dbg(launch_layernorm(dtype16, d_x, c, d_gamma, d_beta, d_y, rows, c,
+                              reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads, int dtype16,
+                         void* stream) {
+  return dbg(launch_attention(dtype16, d_qkv, d_out, n, l, heads,
+                              reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
+  return dbg(launch_tr_read_probe(d_in, d_out, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_set_attention_variant(int use_tr) {
+  oake::g_attention_use_tr = use_tr ? 1 : 0;
+  return OAKE_OK;
+}
+
+}  // extern "C"

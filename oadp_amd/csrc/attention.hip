@@ -1,0 +1,360 @@
+// attention.hip — multi-head self-attention for the ViT token sequences of OAKE
+// (L = 50 for encode_image, L = 197 in objects mode), SURVEY.md §8 A15e and A11.
+//
+// attention_kernel: one wavefront per (crop, head, 64-query block).  Everything stays in
+// registers except V:
+//   * S^T = K Q^T on the matrix cores (K fragment as MFMA A operand, Q fragment as B operand), so a
+//     lane's accumulator column is ONE query: the softmax row reductions are 16 in-register
+//     values + two cross-lane steps (xor 16, 32) instead of a 64-lane butterfly per row.
+//   * the exponentiated S^T accumulators are already in the MFMA B-operand layout for
+//     O^T = V^T P^T if the contraction index (key) is enumerated as
+//        key(ks, g, j) = 32 ks + 16 (j>>2) + 4 g + (j&3),  g = lane>>4, j = 0..7
+//     so P never moves between lanes or through LDS.
+//   * V is staged in wave-private LDS (coalesced 16-B rows in) and read back with the gfx950
+//     transpose read ds_read_b64_tr_b16 in that same key enumeration (USE_TR), or with plain
+//     16-bit gathers (fallback).
+//   * keys are processed in chunks of 64 with an online softmax, so the same kernel serves L = 50
+//     (one chunk) and L = 197 (four chunks).
+// object_attention_kernel: the reference's object-token stream (oadp/oake/objects.py:232-247) has a
+// single query per crop; it is a VALU/LDS kernel, one wavefront per (crop, head).
+#include "common.h"
+#include "kernels.h"
+
+namespace oake {
+
+namespace {
+
+constexpr int kVStride = 72;                       // halves per V row in LDS (64 + 8 pad = 144 B)
+constexpr int kVBytesPerWave = 64 * kVStride * 2;  // 9216
+
+template <typename T, bool USE_TR>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv,
+                                                        T* __restrict__ out, int L, int H, int QB,
+                                                        int total_waves) {
+  typedef typename T16<T>::vec8 vec8;
+  __shared__ __attribute__((aligned(16))) char smem[4 * kVBytesPerWave];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wg = blockIdx.x * 4 + wid;
+  if (wg >= total_waves) return;  // no block-level barriers below: wave-private LDS only
+  const int qb = wg % QB;
+  const int h = (wg / QB) % H;
+  const int img = wg / (QB * H);
+  const int C = H * kHeadDim;
+  const size_t ld = (size_t)3 * C;
+  const T* base = qkv + (size_t)img * L * ld + h * kHeadDim;
+  const int fr = lane & 15;
+  const int g = lane >> 4;
+  const int q0 = qb * 64;
+  T* vs = reinterpret_cast<T*>(smem + wid * kVBytesPerWave);
+
+  // Q fragments (B operand): Q[q0 + 16 mt + fr][32 kk + 8 g .. +8)
+  vec8 qf[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int r = q0 + mt * 16 + fr;
+    r = r < L ? r : L - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[mt][kk] = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + kk * 32 + g * 8);
+  }
+
+  float m_run[4], l_run[4];
+  f32x4 oacc[4][4];  // [dt][mt] : O^T tile, rows d = 16 dt + 4 g + r, col query = 16 mt + fr
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    m_run[mt] = -1e30f;
+    l_run[mt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nchunks = (L + 63) >> 6;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int k0 = kc * 64;
+
+    // ---- stage V[k0 .. k0+64) into LDS: lane -> (row = lane/8 + 8 i, 16-B chunk = lane%8) ----
+    {
+      const int vr = lane >> 3, vc = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int r = k0 + vr + 8 * i;
+        r = r < L ? r : L - 1;  // finite filler for padded keys (their P is exactly 0)
+        const uint4 v =
+            *reinterpret_cast<const uint4*>(base + (size_t)r * ld + 2 * C + vc * 8);
+        *reinterpret_cast<uint4*>(vs + (vr + 8 * i) * kVStride + vc * 8) = v;
+      }
+    }
+
+    // ---- S^T[key][query] tiles ----
+    f32x4 sacc[4][4];  // [kt][mt]
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      int r = k0 + kt * 16 + fr;
+      r = r < L ? r : L - 1;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const vec8 kf =
+            *reinterpret_cast<const vec8*>(base + (size_t)r * ld + C + kk * 32 + g * 8);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
+      }
+    }
+
+    // ---- online softmax over this chunk's keys; lane owns query 16 mt + fr ----
+    vec8 pf[4][2];  // [mt][ks] : B operand of the PV MFMA
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + kt * 16 + 4 * g + r;
+          float s = sacc[kt][mt][r];
+          s = key < L ? s : -1e30f;
+          sacc[kt][mt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[mt], mx);
+      const float alpha = __expf(m_run[mt] - m_new);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(sacc[kt][mt][r] - m_new);
+          sacc[kt][mt][r] = p;
+          sum += p;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      l_run[mt] = l_run[mt] * alpha + sum;
+      m_run[mt] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        oacc[dt][mt][0] *= alpha;
+        oacc[dt][mt][1] *= alpha;
+        oacc[dt][mt][2] *= alpha;
+        oacc[dt][mt][3] *= alpha;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        vec8 p8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p8[j] = to16<T>(sacc[2 * ks + (j >> 2)][mt][j & 3]);
+        pf[mt][ks] = p8;
+      }
+    }
+
+    // LDS writes above and reads below are wave-private; the DS queue is in order per wave.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- O^T[d][query] += V^T[d][key] P^T[key][query] ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        vec8 vf;
+        if (USE_TR) {
+          // ds_read_b64_tr_b16: within a 16-lane group, lane i supplies the address of the 8-B
+          // slice {row i/4, cols 4(i%4)..+3} of a 4x16 block and receives column i of it.
+          const int sub = fr >> 2, c4 = (fr & 3) * 4;
+          const T* p0 = vs + (32 * ks + 4 * g + sub) * kVStride + dt * 16 + c4;
+          const T* p1 = p0 + 16 * kVStride;
+          typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p1));
+          s16x8 both;
+          both[0] = lo[0]; both[1] = lo[1]; both[2] = lo[2]; both[3] = lo[3];
+          both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
+          vf = __builtin_bit_cast(vec8, both);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            vf[j] = vs[(32 * ks + 16 * (j >> 2) + 4 * g + (j & 3)) * kVStride + dt * 16 + fr];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ks], oacc[dt][mt]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- normalise and store: lane holds O[query = 16 mt + fr][d = 16 dt + 4 g + 0..3] ----
+  T* obase = out + (size_t)img * L * C + h * kHeadDim;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int q = q0 + mt * 16 + fr;
+    if (q >= L) continue;
+    const float inv = 1.0f / l_run[mt];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 o = oacc[dt][mt];
+      *reinterpret_cast<uint2*>(obase + (size_t)q * C + dt * 16 + 4 * g) =
+          pack4<T>(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+    }
+  }
+}
+
+// ---- object-token attention -------------------------------------------------------------------
+// One wavefront per (crop n, head h).  query = qkv_y[n].q_h ; keys/values: x rows 1..L-1 of crop n
+// (bias -100*mask[n,p]) then the object token's own k/v from qkv_y[n] (bias 0).
+constexpr int kObjMaxKeys = 1024;
+
+template <typename T, typename TM>
+__global__ __launch_bounds__(256) void object_attention_kernel(const T* __restrict__ qkv_x,
+                                                               const T* __restrict__ qkv_y,
+                                                               const TM* __restrict__ mask,
+                                                               T* __restrict__ out, int L, int H,
+                                                               int total_waves) {
+  __shared__ float ps[4][kObjMaxKeys];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wg = blockIdx.x * 4 + wid;
+  if (wg >= total_waves) return;
+  const int h = wg % H;
+  const int n = wg / H;
+  const int C = H * kHeadDim;
+  const size_t ld = (size_t)3 * C;
+  const int nk = L;  // L-1 patch keys + the object token
+  const T* xb = qkv_x + (size_t)n * L * ld + h * kHeadDim;
+  const T* yb = qkv_y + (size_t)n * ld + h * kHeadDim;
+  const TM* mb = mask + (size_t)n * (L - 1);
+
+  // q in registers (every lane holds the whole 64-vector; loads broadcast)
+  float q[kHeadDim];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    typedef typename T16<T>::vec8 vec8;
+    const vec8 v = *reinterpret_cast<const vec8*>(yb + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[i * 8 + j] = to32<T>(v[j]);
+  }
+
+  // scores: lane handles keys lane, lane + 64, ...
+  float mx = -1e30f;
+  for (int k = lane; k < nk; k += 64) {
+    const T* kr = (k < L - 1) ? (xb + (size_t)(1 + k) * ld + C) : (yb + C);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      typedef typename T16<T>::vec8 vec8;
+      const vec8 v = *reinterpret_cast<const vec8*>(kr + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += q[i * 8 + j] * to32<T>(v[j]);
+    }
+    if (k < L - 1) s += -100.0f * (float)mb[k];
+    ps[wid][k] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k < nk; k += 64) {
+    const float p = __expf(ps[wid][k] - mx);
+    ps[wid][k] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // out[d = lane] = sum_k p[k] V[k][d]
+  float acc = 0.f;
+  for (int k = 0; k < L - 1; ++k)
+    acc += ps[wid][k] * to32<T>(xb[(size_t)(1 + k) * ld + 2 * C + lane]);
+  acc += ps[wid][L - 1] * to32<T>(yb[2 * C + lane]);
+  out[(size_t)n * C + h * kHeadDim + lane] = to16<T>(acc * inv);
+}
+
+__global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) lds[i] = in[i];
+  __syncthreads();
+  typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(lds + lane * 4));
+  for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (uint16_t)v[j];
+}
+
+}  // namespace
+
+// 0 = 16-bit LDS gathers for the V fragments, 1 = ds_read_b64_tr_b16 (set by api.hip)
+int g_attention_use_tr = 0;
+
+hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
+                            hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
+  const int QB = (L + 63) / 64;
+  const long total = (long)n * heads * QB;
+  if (total > 0x7fffffffL) return hipErrorInvalidValue;
+  const int blocks = (int)((total + 3) / 4);
+  const dim3 g(blocks), b(256);
+  const int tw = (int)total;
+  if (dtype16 == DT_F16) {
+    const f16_t* in = reinterpret_cast<const f16_t*>(qkv);
+    f16_t* o = reinterpret_cast<f16_t*>(out);
+    if (g_attention_use_tr)
+      hipLaunchKernelGGL((attention_kernel<f16_t, true>), g, b, 0, s, in, o, L, heads, QB, tw);
+    else
+      hipLaunchKernelGGL((attention_kernel<f16_t, false>), g, b, 0, s, in, o, L, heads, QB, tw);
+  } else if (dtype16 == DT_BF16) {
+    const bf16_t* in = reinterpret_cast<const bf16_t*>(qkv);
+    bf16_t* o = reinterpret_cast<bf16_t*>(out);
+    if (g_attention_use_tr)
+      hipLaunchKernelGGL((attention_kernel<bf16_t, true>), g, b, 0, s, in, o, L, heads, QB, tw);
+    else
+      hipLaunchKernelGGL((attention_kernel<bf16_t, false>), g, b, 0, s, in, o, L, heads, QB, tw);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t obj_attn_t(const void* qkv_x, const void* qkv_y, const void* mask, int mask_dtype,
+                             void* out, int n, int L, int heads, hipStream_t s) {
+  const int total = n * heads;
+  const dim3 g((total + 3) / 4), b(256);
+  if (mask_dtype == DT_F32)
+    hipLaunchKernelGGL((object_attention_kernel<T, float>), g, b, 0, s,
+                       reinterpret_cast<const T*>(qkv_x), reinterpret_cast<const T*>(qkv_y),
+                       reinterpret_cast<const float*>(mask), reinterpret_cast<T*>(out), L, heads,
+                       total);
+  else if (mask_dtype == DT_F16)
+    hipLaunchKernelGGL((object_attention_kernel<T, f16_t>), g, b, 0, s,
+                       reinterpret_cast<const T*>(qkv_x), reinterpret_cast<const T*>(qkv_y),
+                       reinterpret_cast<const f16_t*>(mask), reinterpret_cast<T*>(out), L, heads,
+                       total);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* qkv_y,
+                                   const void* mask, int mask_dtype, void* out, int n, int L,
+                                   int heads, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (L < 2 || L > kObjMaxKeys) return hipErrorInvalidValue;
+  if (dtype16 == DT_F16) return obj_attn_t<f16_t>(qkv_x, qkv_y, mask, mask_dtype, out, n, L, heads, s);
+  if (dtype16 == DT_BF16) return obj_attn_t<bf16_t>(qkv_x, qkv_y, mask, mask_dtype, out, n, L, heads, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(tr_read_probe_kernel, dim3(1), dim3(64), 0, s, in, out);
+  return hipGetLastError();
+}
+
+}  // namespace oake

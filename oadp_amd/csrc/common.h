@@ -1,0 +1,92 @@
+// common.h — shared device helpers for the OAKE gfx950 kernels.
+// Wavefront = 64 lanes everywhere; MFMA operands are 16-bit (f16 or bf16), accumulation fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oake {
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWave = 64;
+constexpr int kHeadDim = 64;  // ViT-B/32, B/16, L/14 all use 64
+
+// ---- 16-bit operand traits -------------------------------------------------------------
+template <typename T>
+struct T16;
+
+template <>
+struct T16<f16_t> {
+  typedef f16x8 vec8;
+  typedef f16x4 vec4;
+  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <>
+struct T16<bf16_t> {
+  typedef bf16x8 vec8;
+  typedef bf16x4 vec4;
+  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ T to16(float x) {
+  return (T)x;  // round-to-nearest-even for both _Float16 and __bf16
+}
+template <typename T>
+__device__ __forceinline__ float to32(T x) {
+  return (float)x;
+}
+
+// 4 floats -> 4 x 16-bit packed into 8 bytes
+template <typename T>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  typename T16<T>::vec4 v;
+  v[0] = to16<T>(a);
+  v[1] = to16<T>(b);
+  v[2] = to16<T>(c);
+  v[3] = to16<T>(d);
+  return __builtin_bit_cast(uint2, v);
+}
+
+// ---- wave reductions --------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// QuickGELU (OpenAI CLIP): x * sigmoid(1.702 x)
+__device__ __forceinline__ float quick_gelu(float x) {
+  return x / (1.0f + __expf(-1.702f * x));
+}
+
+// XCD-aware bijective block remap (guide T1): hardware places block b on XCD b % 8; give each
+// XCD a contiguous range of logical tiles so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  const int q = nwg / nx, r = nwg % nx;
+  const int xcd = bid % nx, idx = bid / nx;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace oake

@@ -1,0 +1,82 @@
+// kernels.h — host-side launcher declarations shared by the translation units of liboake_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oake {
+
+// 16-bit operand type selector (matches OAKE_F16 / OAKE_BF16 in include/oake_hip.h)
+enum { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2, DT_U8 = 3 };
+
+// ---- GEMM: C[M,N] = A[M,K] * W[N,K]^T, 16-bit operands, fp32 accumulate -------------------
+enum GemmEpi {
+  EPI_F32_BIAS = 0,   // out fp32 [M,ldo] = acc + bias                 (debug / tests)
+  EPI_T16_BIAS = 1,   // out T16 [M,ldo] = acc + bias                  (QKV in-proj)
+  EPI_T16_GELU = 2,   // out T16 [M,ldo] = quick_gelu(acc + bias)      (MLP c_fc)
+  EPI_RESID = 3,      // out fp32 [M,ldo] += acc + bias                (attn out_proj, MLP c_proj)
+  EPI_PATCH = 4       // out fp32 x[(m/P2)*L + 1 + m%P2, :] = acc + pos[1 + m%P2, :]   (conv1)
+};
+
+struct GemmArgs {
+  const void* A;      // [M,K] row-major 16-bit
+  const void* W;      // [N,K] row-major 16-bit
+  const float* bias;  // [N] or nullptr
+  void* out;
+  int M, N, K;
+  int ldo;            // leading dimension of out (elements)
+  // EPI_PATCH only
+  const float* pos;   // [L, N] positional embedding (fp32)
+  int P2;             // patches per image
+  int L;              // tokens per image (P2 + 1)
+};
+
+hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
+
+// ---- row kernels -------------------------------------------------------------------------
+// y(16-bit)[rows,c] = LN(x fp32 [rows, c]) ; x rows are `x_row_stride` floats apart.
+hipError_t launch_layernorm(int dtype16, const float* x, long x_row_stride, const float* gamma,
+                            const float* beta, void* y, int rows, int c, hipStream_t s);
+
+// x[n*L + t, :] (fp32, in place): t == 0 -> cls + pos[0]; then ln_pre over every row.
+hipError_t launch_embed_ln_pre(float* x, const float* cls, const float* pos, const float* gamma,
+                               const float* beta, int n, int L, int c, hipStream_t s);
+
+// y[n, :] = x[n*L + 0, :]  (objects mode: object-token stream starts as the CLS row)
+hipError_t launch_copy_cls(const float* x, float* y, int n, int L, int c, hipStream_t s);
+
+// im2col of NCHW images into the conv1 GEMM A operand [n*G*G, 3*P*P] (16-bit).
+hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, int n, int image,
+                         int patch, int stride, int pad, int grid, hipStream_t s);
+
+// ---- attention ---------------------------------------------------------------------------
+// qkv [n*L, 3*H*64] 16-bit (q pre-scaled by 1/8) -> out [n*L, H*64] 16-bit. Full self-attention.
+hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
+                            hipStream_t s);
+
+// Object-token attention (oadp/oake/objects.py:232-247): one query per crop (qkv_y row n),
+// keys/values = patch rows 1..L-1 of qkv_x plus the object token's own k/v (qkv_y);
+// additive bias = -100 * mask[n, p] on patch keys, 0 on the object token.
+hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* qkv_y,
+                                   const void* mask, int mask_dtype, void* out, int n, int L,
+                                   int heads, hipStream_t s);
+
+// ---- head --------------------------------------------------------------------------------
+// rows[n] = x + n*row_stride (fp32, c wide): ln_post -> @ proj[c, e] (16-bit) -> optional L2
+// normalise -> out [n, e] (fp32 or f16).
+hipError_t launch_head(int dtype16, const float* x, long row_stride, const float* gamma,
+                       const float* beta, const void* proj, void* out, int out_dtype,
+                       int normalize, int n, int c, int e, hipStream_t s);
+
+// ---- misc --------------------------------------------------------------------------------
+hipError_t launch_cast_f32_to_16(int dtype16, const float* in, void* out, size_t numel, float scale,
+                                 hipStream_t s);
+// scale rows [row0,row1) of a [rows, cols] fp32 matrix / vector prefix in place
+hipError_t launch_scale_f32(float* x, size_t numel, float scale, hipStream_t s);
+
+hipError_t launch_crop_normalize(const uint8_t* img, int height, int width, const int32_t* boxes,
+                                 int k, int out_size, const float* mean3, const float* inv_std3,
+                                 void* out, int out_dtype, hipStream_t s);
+
+hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s);
+
+}  // namespace oake

@@ -1,0 +1,450 @@
+// rowops.hip — the HBM/L2-bound glue of the encoder (SURVEY.md §8 A15b,c,h): LayerNorm rows with
+// wavefront-shuffle reductions, CLS/pos-emb embedding + ln_pre, im2col for conv1, the
+// ln_post -> proj -> L2-normalise head, weight casts, and the uint8 crop+normalise gather.
+// Every kernel moves 8-16 B per lane per access and keeps the row statistics in registers.
+#include "common.h"
+#include "kernels.h"
+
+namespace oake {
+
+namespace {
+
+constexpr float kLnEps = 1e-5f;
+constexpr int kMaxVec = 4;  // float4 per lane -> rows up to 4*4*64 = 1024 wide
+
+// Loads one fp32 row (c = 4*nv floats) into v[], returns mean/rstd via wave shuffles.
+__device__ __forceinline__ void ln_stats(const float4 (&v)[kMaxVec], int lane, int nv, int c,
+                                         float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  s = wave_sum(s);
+  mean = s / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  q = wave_sum(q);
+  rstd = rsqrtf(q / (float)c + kLnEps);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long stride,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        T* __restrict__ y, int rows, int c) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = c >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * stride);
+  float4 v[kMaxVec];
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) v[i] = xr[lane + 64 * i];
+  float mean, rstd;
+  ln_stats(v, lane, nv, c, mean, rstd);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  uint2* yr = reinterpret_cast<uint2*>(y + (size_t)row * c);
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) {
+      const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
+      yr[lane + 64 * i] = pack4<T>((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                   (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+    }
+}
+
+// x[n*L + t] in place: t == 0 takes cls + pos[0] (patch rows already carry conv + pos from the
+// EPI_PATCH GEMM epilogue), then ln_pre.
+__global__ __launch_bounds__(256) void embed_ln_pre_kernel(float* __restrict__ x,
+                                                           const float* __restrict__ cls,
+                                                           const float* __restrict__ pos,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int rows,
+                                                           int L, int c) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = c >> 2;
+  float4* xr = reinterpret_cast<float4*>(x + (size_t)row * c);
+  const bool is_cls = (row % L) == 0;
+  const float4* c4 = reinterpret_cast<const float4*>(cls);
+  const float4* p4 = reinterpret_cast<const float4*>(pos);
+  float4 v[kMaxVec];
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) {
+      if (is_cls) {
+        const float4 a = c4[lane + 64 * i], b = p4[lane + 64 * i];
+        v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+      } else {
+        v[i] = xr[lane + 64 * i];
+      }
+    }
+  float mean, rstd;
+  ln_stats(v, lane, nv, c, mean, rstd);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) {
+      const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
+      xr[lane + 64 * i] =
+          make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                      (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+    }
+}
+
+__global__ void copy_cls_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int L,
+                                int c) {
+  const int nv = c >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * nv) return;
+  const int img = idx / nv, j = idx % nv;
+  reinterpret_cast<float4*>(y)[idx] =
+      reinterpret_cast<const float4*>(x + (size_t)img * L * c)[j];
+}
+
+// ---- im2col -----------------------------------------------------------------------------
+template <typename TIN>
+__device__ __forceinline__ float load_px(const TIN* p) {
+  return (float)(*p);
+}
+
+template <typename T, typename TIN>
+__global__ __launch_bounds__(256) void im2col_kernel(const TIN* __restrict__ img,
+                                                     T* __restrict__ out, long total8, int image,
+                                                     int patch, int stride, int pad, int grid) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total8) return;
+  const int p8 = patch >> 3;               // 8-element chunks per patch row
+  const int k8_per_row = 3 * patch * p8;   // chunks per A row
+  const long m = idx / k8_per_row;
+  const int k8 = idx - m * k8_per_row;
+  const int kx0 = (k8 % p8) << 3;
+  const int ky = (k8 / p8) % patch;
+  const int ch = k8 / (p8 * patch);
+  const int g2 = grid * grid;
+  const long n = m / g2;
+  const int gi = m - n * g2;
+  const int gy = gi / grid, gx = gi - gy * grid;
+  const int iy = gy * stride - pad + ky;
+  const int ix0 = gx * stride - pad + kx0;
+  float v[8];
+  if (iy < 0 || iy >= image) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  } else {
+    const TIN* row = img + (((size_t)n * 3 + ch) * image + iy) * image;
+    if (ix0 >= 0 && ix0 + 8 <= image) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = load_px(row + ix0 + j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ix = ix0 + j;
+        v[j] = (ix >= 0 && ix < image) ? load_px(row + ix) : 0.f;
+      }
+    }
+  }
+  uint4 o;
+  const uint2 lo = pack4<T>(v[0], v[1], v[2], v[3]);
+  const uint2 hi = pack4<T>(v[4], v[5], v[6], v[7]);
+  o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+  reinterpret_cast<uint4*>(out)[idx] = o;
+}
+
+// ---- head: ln_post -> @proj -> (L2 normalise) -> out ----------------------------------------
+constexpr int kHeadImgs = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, long row_stride,
+                                                   const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta,
+                                                   const T* __restrict__ proj, void* __restrict__ out,
+                                                   int out_f16, int normalize, int n, int c, int e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ys = reinterpret_cast<float*>(smem);          // [kHeadImgs][c]
+  float* red = ys + kHeadImgs * c;                      // [kHeadImgs][4]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int img0 = blockIdx.x * kHeadImgs;
+
+  {  // LayerNorm of image img0 + wid by wave wid
+    const int img = img0 + wid;
+    const int nv = c >> 2;
+    float4 v[kMaxVec];
+    const bool valid = img < n;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)(valid ? img : 0) * row_stride);
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i)
+      if (lane + 64 * i < nv) v[i] = xr[lane + 64 * i];
+    float mean, rstd;
+    ln_stats(v, lane, nv, c, mean, rstd);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4* yw = reinterpret_cast<float4*>(ys + wid * c);
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i)
+      if (lane + 64 * i < nv) {
+        const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
+        yw[lane + 64 * i] =
+            make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                        (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      }
+  }
+  __syncthreads();
+
+  float ssq[kHeadImgs] = {0.f, 0.f, 0.f, 0.f};
+  // each thread owns output columns j = 2*tid + 512*r (+1)
+  const int nrep = (e + 511) / 512;
+  float acc[2][kHeadImgs][2];  // up to e = 1024
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < kHeadImgs; ++i) acc[r][i][0] = acc[r][i][1] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r >= nrep) break;
+    const int j = 2 * tid + 512 * r;
+    if (j < e) {
+      for (int k = 0; k < c; ++k) {
+        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(proj + (size_t)k * e + j);
+        typedef T pair_t __attribute__((ext_vector_type(2)));
+        const pair_t w = __builtin_bit_cast(pair_t, w2);
+        const float w0 = to32<T>(w[0]), w1 = to32<T>(w[1]);
+#pragma unroll
+        for (int i = 0; i < kHeadImgs; ++i) {
+          const float yv = ys[i * c + k];
+          acc[r][i][0] += yv * w0;
+          acc[r][i][1] += yv * w1;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kHeadImgs; ++i)
+        ssq[i] += acc[r][i][0] * acc[r][i][0] + acc[r][i][1] * acc[r][i][1];
+    }
+  }
+  float scale[kHeadImgs];
+  if (normalize) {
+#pragma unroll
+    for (int i = 0; i < kHeadImgs; ++i) {
+      const float s = wave_sum(ssq[i]);
+      if (lane == 0) red[i * 4 + wid] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kHeadImgs; ++i) {
+      const float tot = (red[i * 4 + 0] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);  // F.normalize eps
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kHeadImgs; ++i) scale[i] = 1.0f;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r >= nrep) break;
+    const int j = 2 * tid + 512 * r;
+    if (j >= e) continue;
+#pragma unroll
+    for (int i = 0; i < kHeadImgs; ++i) {
+      const int img = img0 + i;
+      if (img >= n) continue;
+      const float o0 = acc[r][i][0] * scale[i], o1 = acc[r][i][1] * scale[i];
+      if (out_f16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 hv;
+        hv[0] = (_Float16)o0;
+        hv[1] = (_Float16)o1;
+        *reinterpret_cast<h2*>(reinterpret_cast<_Float16*>(out) + (size_t)img * e + j) = hv;
+      } else {
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (size_t)img * e + j) =
+            make_float2(o0, o1);
+      }
+    }
+  }
+}
+
+// ---- casts ----------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, size_t numel,
+                            float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < numel) out[i] = to16<T>(in[i] * scale);
+}
+
+__global__ void scale_kernel(float* __restrict__ x, size_t numel, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < numel) x[i] *= scale;
+}
+
+// ---- crop + ToTensor + Normalize (no resampling: box is out x out) ---------------------------
+template <typename TOUT>
+__global__ __launch_bounds__(256) void crop_normalize_kernel(const uint8_t* __restrict__ img,
+                                                             int height, int width,
+                                                             const int32_t* __restrict__ boxes,
+                                                             int out_size, float m0, float m1,
+                                                             float m2, float s0, float s1, float s2,
+                                                             TOUT* __restrict__ out) {
+  // grid: (ceil(out*out/256), k)
+  const int k = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= out_size * out_size) return;
+  const int oy = p / out_size, ox = p - oy * out_size;
+  const int x1 = boxes[4 * k + 0], y1 = boxes[4 * k + 1];
+  const int sx = x1 + ox, sy = y1 + oy;
+  float r = 0.f, g = 0.f, b = 0.f;  // PIL crop pads with zeros outside the image
+  if (sx >= 0 && sx < width && sy >= 0 && sy < height) {
+    const uint8_t* px = img + ((size_t)sy * width + sx) * 3;
+    r = (float)px[0];
+    g = (float)px[1];
+    b = (float)px[2];
+  }
+  // ToTensor: /255 in fp32 ; Normalize: (x - mean) / std in fp32 — same operation order
+  const size_t plane = (size_t)out_size * out_size;
+  TOUT* o = out + (size_t)k * 3 * plane + p;
+  o[0] = (TOUT)((r / 255.0f - m0) / s0);
+  o[plane] = (TOUT)((g / 255.0f - m1) / s1);
+  o[2 * plane] = (TOUT)((b / 255.0f - m2) / s2);
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(int dtype16, const float* x, long x_row_stride, const float* gamma,
+                            const float* beta, void* y, int rows, int c, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
+  const int blocks = (rows + 3) / 4;
+  if (dtype16 == DT_F16)
+    hipLaunchKernelGGL(layernorm_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, x, x_row_stride,
+                       gamma, beta, reinterpret_cast<f16_t*>(y), rows, c);
+  else if (dtype16 == DT_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, x_row_stride,
+                       gamma, beta, reinterpret_cast<bf16_t*>(y), rows, c);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_embed_ln_pre(float* x, const float* cls, const float* pos, const float* gamma,
+                               const float* beta, int n, int L, int c, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
+  const int rows = n * L;
+  hipLaunchKernelGGL(embed_ln_pre_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, cls, pos, gamma,
+                     beta, rows, L, c);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_cls(const float* x, float* y, int n, int L, int c, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const long total = (long)n * (c >> 2);
+  hipLaunchKernelGGL(copy_cls_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, y, n, L, c);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t im2col_in(const void* img, int in_dtype, void* out, long total8, int image,
+                            int patch, int stride, int pad, int grid, hipStream_t s) {
+  const dim3 g((total8 + 255) / 256), b(256);
+  T* o = reinterpret_cast<T*>(out);
+  switch (in_dtype) {
+    case DT_F32:
+      hipLaunchKernelGGL((im2col_kernel<T, float>), g, b, 0, s,
+                         reinterpret_cast<const float*>(img), o, total8, image, patch, stride, pad,
+                         grid);
+      break;
+    case DT_F16:
+      hipLaunchKernelGGL((im2col_kernel<T, f16_t>), g, b, 0, s,
+                         reinterpret_cast<const f16_t*>(img), o, total8, image, patch, stride, pad,
+                         grid);
+      break;
+    case DT_BF16:
+      hipLaunchKernelGGL((im2col_kernel<T, bf16_t>), g, b, 0, s,
+                         reinterpret_cast<const bf16_t*>(img), o, total8, image, patch, stride, pad,
+                         grid);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, int n, int image,
+                         int patch, int stride, int pad, int grid, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (patch % 8 != 0) return hipErrorInvalidValue;
+  const long total8 = (long)n * grid * grid * 3 * patch * (patch / 8);
+  if (dtype16 == DT_F16)
+    return im2col_in<f16_t>(img, in_dtype, out, total8, image, patch, stride, pad, grid, s);
+  if (dtype16 == DT_BF16)
+    return im2col_in<bf16_t>(img, in_dtype, out, total8, image, patch, stride, pad, grid, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_head(int dtype16, const float* x, long row_stride, const float* gamma,
+                       const float* beta, const void* proj, void* out, int out_dtype, int normalize,
+                       int n, int c, int e, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (c % 4 != 0 || c > kMaxVec * 256 || e % 2 != 0 || e > 1024) return hipErrorInvalidValue;
+  if (out_dtype != DT_F32 && out_dtype != DT_F16) return hipErrorInvalidValue;
+  const int blocks = (n + kHeadImgs - 1) / kHeadImgs;
+  const size_t lds = (size_t)kHeadImgs * c * sizeof(float) + kHeadImgs * 4 * sizeof(float);
+  const int of16 = out_dtype == DT_F16;
+  if (dtype16 == DT_F16)
+    hipLaunchKernelGGL(head_kernel<f16_t>, dim3(blocks), dim3(256), lds, s, x, row_stride, gamma,
+                       beta, reinterpret_cast<const f16_t*>(proj), out, of16, normalize, n, c, e);
+  else if (dtype16 == DT_BF16)
+    hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, x, row_stride, gamma,
+                       beta, reinterpret_cast<const bf16_t*>(proj), out, of16, normalize, n, c, e);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_cast_f32_to_16(int dtype16, const float* in, void* out, size_t numel, float scale,
+                                 hipStream_t s) {
+  if (numel == 0) return hipSuccess;
+  const dim3 g((numel + 255) / 256), b(256);
+  if (dtype16 == DT_F16)
+    hipLaunchKernelGGL(cast_kernel<f16_t>, g, b, 0, s, in, reinterpret_cast<f16_t*>(out), numel,
+                       scale);
+  else if (dtype16 == DT_BF16)
+    hipLaunchKernelGGL(cast_kernel<bf16_t>, g, b, 0, s, in, reinterpret_cast<bf16_t*>(out), numel,
+                       scale);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_f32(float* x, size_t numel, float scale, hipStream_t s) {
+  if (numel == 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_kernel, dim3((numel + 255) / 256), dim3(256), 0, s, x, numel, scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_crop_normalize(const uint8_t* img, int height, int width, const int32_t* boxes,
+                                 int k, int out_size, const float* mean3, const float* std3,
+                                 void* out, int out_dtype, hipStream_t s) {
+  if (k <= 0) return hipSuccess;
+  const dim3 g((out_size * out_size + 255) / 256, k), b(256);
+  if (out_dtype == DT_F32)
+    hipLaunchKernelGGL(crop_normalize_kernel<float>, g, b, 0, s, img, height, width, boxes, out_size,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+                       reinterpret_cast<float*>(out));
+  else if (out_dtype == DT_F16)
+    hipLaunchKernelGGL(crop_normalize_kernel<f16_t>, g, b, 0, s, img, height, width, boxes, out_size,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+                       reinterpret_cast<f16_t*>(out));
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace oake

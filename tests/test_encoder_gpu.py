@@ -1,0 +1,115 @@
+"""End-to-end parity of the HIP encoder (through oadp_amd.clip -> C ABI) against the fp32 CPU
+oracle on the same seeded weights and inputs.  Tolerance = BASELINE.json north_star: fp16
+rtol 1e-3 / atol 1e-3 on L2-normalised features and cosine >= 0.999."""
+import pytest
+import torch
+
+from oadp_amd import clip
+from oadp_amd.weights import synthetic_images, synthetic_state_dict
+from oracle.vit_ref import ViTConfig, encode_image_ref, encode_objects_ref, l2_normalize
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(width=128, layers=2, heads=2, mlp_dim=512, embed_dim=64)
+
+
+def _check(out, ref, rtol, atol, cos_min=0.999):
+    out = out.float().cpu()
+    cos = torch.nn.functional.cosine_similarity(out, ref, dim=1)
+    err = (out - ref).abs().max().item()
+    print(f'max|err|={err:.3e} min cos={cos.min().item():.6f}')
+    assert cos.min().item() >= cos_min
+    torch.testing.assert_close(out, ref, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('dtype,rtol,atol', [(torch.float16, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-3)])
+@pytest.mark.parametrize('n', [1, 5, 27])
+def test_encode_image_tiny(cuda, dtype, rtol, atol, n):
+    sd = synthetic_state_dict(**TINY)
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=16)
+    x = synthetic_images(n, seed=n)
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(**TINY), x))
+    out = model.encode_image(x.to(cuda), normalize=True, out_dtype=torch.float32)
+    _check(out, ref, rtol, atol)
+    # un-normalised surface (what the reference's encode_image returns), f16 like model.dtype
+    raw = model.encode_image(x.to(cuda))
+    assert raw.dtype == dtype and raw.shape == (n, TINY['embed_dim'])
+    _check(torch.nn.functional.normalize(raw.float()), ref, 3 * rtol, 3 * atol)
+
+
+def test_encode_image_vit_b32(cuda):
+    """Full ViT-B/32 (SURVEY.md §3.4 constants), 12 layers, 87.8 M parameters."""
+    sd = synthetic_state_dict()
+    model, _ = clip.load(sd, max_batch=8)
+    x = synthetic_images(11, seed=3)  # 11 > max_batch: exercises the multi-pass path
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
+    out = model.encode_image(x.to(cuda), normalize=True, out_dtype=torch.float16)
+    assert out.dtype == torch.float16 and out.shape == (11, 512)
+    _check(out, ref, 1e-3, 1e-3)
+    # half-precision input (the reference casts images to model.dtype before conv1)
+    out16 = model.encode_image(x.half().to(cuda), normalize=True, out_dtype=torch.float32)
+    ref16 = l2_normalize(encode_image_ref(sd, ViTConfig(), x.half().float()))
+    _check(out16, ref16, 1e-3, 1e-3)
+
+
+def test_encode_image_batch_invariance(cuda):
+    """The per-image .pth contract: an image's feature must not depend on its batch."""
+    sd = synthetic_state_dict(**TINY)
+    model, _ = clip.load(sd, max_batch=64)
+    x = synthetic_images(33, seed=9).to(cuda)
+    full = model.encode_image(x, normalize=True, out_dtype=torch.float32)
+    one = torch.cat([model.encode_image(x[i:i + 1], normalize=True, out_dtype=torch.float32)
+                     for i in (0, 17, 32)])
+    assert torch.equal(full[[0, 17, 32]], one)
+
+
+def _objects_model(sd, arch, dtype=torch.float16, max_batch=8):
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=max_batch)
+    v = model.visual
+    # the reference's surgery, oadp/oake/objects.py:292-301
+    v.positional_embedding = v.interpolate_positional_embedding((v.grid * 2,) * 2)
+    v.grid *= 2
+    v.conv1.stride = tuple(s // 2 for s in v.conv1.stride)
+    v.conv1.padding = ((v.patch_size - 1) // 2,) * 2
+    v.object_stream = True
+    sd2 = dict(sd)
+    sd2['visual.positional_embedding'] = v.positional_embedding
+    cfg = ViTConfig(**arch, stride=v.conv1.stride[0], padding=v.conv1.padding[0])
+    return model, sd2, cfg
+
+
+@pytest.mark.parametrize('n', [1, 3, 11])
+def test_encode_objects_tiny(cuda, n):
+    sd = synthetic_state_dict(**TINY)
+    model, sd2, cfg = _objects_model(sd, TINY)
+    assert cfg.grid == 14 and cfg.tokens == 197
+    x = synthetic_images(n, seed=20 + n)
+    g = torch.Generator().manual_seed(n)
+    masks = (torch.rand(n, 1, 14, 14, generator=g) > 0.4).float()
+    masks[0] = 0  # an all-foreground crop
+    ref = l2_normalize(encode_objects_ref(sd2, cfg, x, masks))
+    out = model.visual(x.to(cuda), masks.to(cuda), normalize=True, out_dtype=torch.float32)
+    _check(out, ref, 1e-3, 1e-3)
+
+
+def test_encode_objects_vit_b32(cuda):
+    sd = synthetic_state_dict()
+    model, sd2, cfg = _objects_model(sd, {}, max_batch=4)
+    x = synthetic_images(5, seed=77)
+    g = torch.Generator().manual_seed(5)
+    masks = (torch.rand(5, 1, 14, 14, generator=g) > 0.5).float()
+    ref = l2_normalize(encode_objects_ref(sd2, cfg, x, masks))
+    out = model.visual(x.to(cuda), masks.half().to(cuda), normalize=True, out_dtype=torch.float16)
+    _check(out, ref, 1e-3, 1e-3)
+
+
+def test_errors_are_loud(cuda):
+    sd = synthetic_state_dict(**TINY)
+    model, _ = clip.load(sd)
+    with pytest.raises(RuntimeError):
+        model.encode_image(synthetic_images(1))  # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        model.encode_image(torch.zeros(1, 3, 100, 100, device=cuda))
+    with pytest.raises(ValueError):
+        model.visual(torch.zeros(1, 3, 224, 224, device=cuda), torch.zeros(1, 1, 14, 14, device=cuda))
+    assert model.encode_image(torch.zeros(0, 3, 224, 224, device=cuda)).shape == (0, 64)

@@ -1,0 +1,96 @@
+"""Kernel-level parity on the GPU, through the C ABI debug entry points (include/oake_hip.h).
+
+Each HIP kernel is compared with a plain PyTorch fp32 reference of the same op computed from the
+SAME 16-bit-rounded operands, so the tolerance only has to cover fp32 accumulation order and the
+16-bit rounding of outputs.  Inputs are asymmetric random (a transposed C-write cannot pass).
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+from oadp_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DT = {torch.float16: _lib.OAKE_F16, torch.bfloat16: _lib.OAKE_BF16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('m,n,k', [(128, 128, 64), (256, 384, 128), (1350, 768, 768),
+                                   (50, 2304, 768), (77, 132, 3072), (12800, 768, 3072)])
+def test_gemm(lib, cuda, dtype, m, n, k):
+    g = torch.Generator(device='cpu').manual_seed(m * 7 + n * 3 + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(dtype).to(cuda)
+    bias = torch.randn(n, generator=g).to(cuda)
+    c = torch.full((m, n), float('nan'), device=cuda)
+    rc = lib.oake_debug_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k,
+                             DT[dtype], _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t() + bias
+    torch.testing.assert_close(c, ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('rows,c', [(1, 768), (50, 768), (12800, 768), (7, 128), (33, 1024)])
+def test_layernorm(lib, cuda, dtype, rows, c):
+    g = torch.Generator(device='cpu').manual_seed(rows + c)
+    x = (torch.randn(rows, c, generator=g) * 3 + 0.7).to(cuda)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(cuda)
+    beta = (0.1 * torch.randn(c, generator=g)).to(cuda)
+    y = torch.zeros(rows, c, dtype=dtype, device=cuda)
+    rc = lib.oake_debug_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                  rows, c, DT[dtype], _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (c,), gamma, beta, 1e-5)
+    tol = 2e-3 if dtype == torch.float16 else 2e-2
+    torch.testing.assert_close(y.float(), ref, rtol=tol, atol=tol)
+
+
+def _attention_ref(qkv, n, l, heads):
+    c = heads * 64
+    q, k, v = qkv.float().view(n, l, 3, heads, 64).permute(2, 0, 3, 1, 4)  # [n, h, l, 64]
+    p = torch.softmax(q @ k.transpose(-1, -2), dim=-1)  # q is pre-scaled
+    return (p @ v).permute(0, 2, 1, 3).reshape(n * l, c)
+
+
+@pytest.mark.parametrize('use_tr', [0, 1])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('n,l,heads', [(1, 50, 2), (3, 50, 12), (2, 197, 2), (5, 64, 3), (2, 17, 1),
+                                       (1, 130, 1)])
+def test_attention(lib, cuda, dtype, n, l, heads, use_tr):
+    g = torch.Generator(device='cpu').manual_seed(n * 100 + l + heads)
+    qkv = torch.randn(n * l, 3 * heads * 64, generator=g)
+    qkv[:, :heads * 64] *= 0.35  # pre-scaled q: scores ~ N(0, 2.8^2): a peaky softmax
+    qkv = qkv.to(dtype).to(cuda)
+    out = torch.zeros(n * l, heads * 64, dtype=dtype, device=cuda)
+    lib.oake_debug_set_attention_variant(use_tr)
+    try:
+        rc = lib.oake_debug_attention(qkv.data_ptr(), out.data_ptr(), n, l, heads, DT[dtype], _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.oake_debug_set_attention_variant(0)
+    ref = _attention_ref(qkv, n, l, heads)
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
+
+
+def test_tr_read_semantics(lib, cuda):
+    """ds_read_b64_tr_b16: lane i of a 16-lane group, addressing the 8-B slice i of a row-major
+    4x16 block of 16-bit elements, receives column i of that block."""
+    src = torch.arange(256, dtype=torch.int16, device=cuda)
+    out = torch.zeros(256, dtype=torch.int16, device=cuda)
+    assert lib.oake_debug_tr_read(src.data_ptr(), out.data_ptr(), _stream()) == 0
+    torch.cuda.synchronize()
+    got = out.view(64, 4).cpu()
+    lanes = torch.arange(64)
+    exp = torch.stack([64 * (lanes // 16) + 16 * j + (lanes % 16) for j in range(4)], dim=1)
+    assert torch.equal(got, exp.to(torch.int16)), f'tr-read mapping differs:\n{got}'
