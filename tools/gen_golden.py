@@ -1,0 +1,401 @@
+"""Mint golden fixtures from the REFERENCE's own OAKE code (run in the build container only).
+
+`/root/reference/oadp/oake/{base,globals,blocks,objects}.py` import `clip`, `todd`, `torchvision`
+(none installed, none vendored — SURVEY.md §0.2).  This script registers import-time stubs for
+those packages, loads the four reference modules from where they lie, drives their own functions
+and dumps small numeric fixtures into tests/golden/.  Nothing of the reference's text is copied:
+the fixtures are inputs + the outputs the reference code produced.
+
+    python tools/gen_golden.py            # writes tests/golden/*.json / *.npz
+
+What runs reference code verbatim:  blocks.Dataset._partition/_partitions/_bbox/_preprocess,
+objects.COCODataset._mask/_expand/_preprocess, objects.Hooks, objects.Validator._build_model.
+What is stubbed (our inference of un-vendored behaviour, labelled as such in the fixtures):
+  * todd.BBoxesXYXY / BBoxesCXCYWH semantics (SURVEY.md §8c row `_expand`),
+  * the torchvision transform (PIL bicubic resize + centre crop + ToTensor + Normalize),
+  * a stand-in torch ViT exposing the attribute names the reference's Hooks touch.
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import pathlib
+import sys
+import types
+
+import numpy as np
+import PIL.Image
+import torch
+import torch.nn as nn
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+REF = pathlib.Path('/root/reference')
+OUT = ROOT / 'tests' / 'golden'
+sys.path.insert(0, str(ROOT))
+
+
+# ---------------------------------------------------------------------------- stubs
+class _Generic:
+    def __class_getitem__(cls, item):
+        return cls
+
+
+class BBoxesXYXY:
+    """Inferred todd semantics: tensor [n,4] x1,y1,x2,y2."""
+
+    def __init__(self, t):
+        self._t = torch.as_tensor(t, dtype=torch.float32).reshape(-1, 4)
+
+    def to_tensor(self):
+        return self._t
+
+    def __len__(self):
+        return self._t.shape[0]
+
+    def __getitem__(self, idx):
+        return type(self)(self._t[idx])
+
+    def __iter__(self):
+        for row in self._xyxy():
+            yield tuple(row.tolist())
+
+    def _xyxy(self):
+        return self._t
+
+    @property
+    def lt(self):
+        return self._xyxy()[:, :2]
+
+    @property
+    def rb(self):
+        return self._xyxy()[:, 2:]
+
+    @property
+    def wh(self):
+        return self.rb - self.lt
+
+    @property
+    def center(self):
+        return (self.lt + self.rb) / 2
+
+    @property
+    def area(self):
+        wh = self.wh
+        return wh[:, 0] * wh[:, 1]
+
+    def indices(self, min_wh=None):
+        wh = self.wh
+        return (wh[:, 0] >= min_wh[0]) & (wh[:, 1] >= min_wh[1])
+
+    def translate(self, offset):
+        offset = torch.as_tensor(offset, dtype=torch.float32)
+        return BBoxesXYXY(self._xyxy() + torch.cat([offset, offset], dim=-1))
+
+    def to(self, cls):
+        return cls(self._xyxy()) if cls is BBoxesXYXY else cls.from_xyxy(self._xyxy())
+
+
+class BBoxesCXCYWH(BBoxesXYXY):
+
+    def __init__(self, t):
+        self._t = torch.as_tensor(t, dtype=torch.float32).reshape(-1, 4)
+
+    def _xyxy(self):
+        c, wh = self._t[:, :2], self._t[:, 2:]
+        return torch.cat([c - wh / 2, c + wh / 2], dim=-1)
+
+
+class _Registry(_Generic):
+    @classmethod
+    def register(cls, *a, **k):
+        return lambda c: c
+
+    @classmethod
+    def build(cls, *a, **k):
+        raise NotImplementedError
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Store:
+        DRY_RUN = False
+        CUDA = False
+        CPU = True
+
+    class Validator(_Generic):
+        def __init__(self, *a, **k):
+            pass
+
+    clip_model = mod('clip.model', CLIP=object, Transformer=nn.Module,
+                     ResidualAttentionBlock=nn.Module)
+    mod('clip', model=clip_model, load_default=None)
+    utils = mod('todd.utils', Validator=Validator, Memo=dict, Control=object)
+    base = mod('todd.base', DictAction=object)
+    mod('todd', utils=utils, base=base, Store=Store, Config=dict, Registry=_Registry,
+        BBox=tuple, BBoxes=BBoxesXYXY, BBoxesXYXY=BBoxesXYXY, BBoxesCXCYWH=BBoxesCXCYWH,
+        logger=types.SimpleNamespace(info=print), get_local_rank=lambda: 0)
+
+    class CocoDetection(_Generic):
+        def __init__(self, *a, **k):
+            pass
+
+    tvd = mod('torchvision.datasets', CocoDetection=CocoDetection)
+    tvt = mod('torchvision.transforms', Compose=object)
+    mod('torchvision', datasets=tvd, transforms=tvt)
+    for pkg in ('oadp', 'oadp.oake'):
+        m = mod(pkg)
+        m.__path__ = [str(REF / pkg.replace('.', '/'))]
+
+
+def load_ref(name: str):
+    spec = importlib.util.spec_from_file_location(f'oadp.oake.{name}', REF / 'oadp' / 'oake' / f'{name}.py')
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+# ---------------------------------------------------------------------------- transform stand-in
+MEAN = (0.48145466, 0.4578275, 0.40821073)
+STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def tv_transform(image: PIL.Image.Image, n: int = 224) -> torch.Tensor:
+    """Stand-in for torchvision Compose([Resize(n, BICUBIC), CenterCrop(n), RGB, ToTensor, Normalize])."""
+    image = image.convert('RGB')
+    w, h = image.size
+    if not ((w <= h and w == n) or (h <= w and h == n)):
+        if w < h:
+            image = image.resize((n, int(n * h / w)), PIL.Image.BICUBIC)
+        else:
+            image = image.resize((int(n * w / h), n), PIL.Image.BICUBIC)
+    w, h = image.size
+    left, top = int(round((w - n) / 2.0)), int(round((h - n) / 2.0))
+    image = image.crop((left, top, left + n, top + n))
+    t = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+    return t.sub(torch.tensor(MEAN).view(3, 1, 1)).div(torch.tensor(STD).view(3, 1, 1))
+
+
+def synth_image(w: int, h: int, seed: int) -> PIL.Image.Image:
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)),
+                     ((xx + yy) * 255 // max(w + h - 2, 1))], axis=-1).astype(np.int32)
+    noise = rng.integers(-40, 41, size=(h, w, 3))
+    return PIL.Image.fromarray(np.clip(base + noise, 0, 255).astype(np.uint8), 'RGB')
+
+
+# ---------------------------------------------------------------------------- stand-in ViT
+class StandinBlock(nn.Module):
+    def __init__(self, width, heads, mlp):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(width, heads)
+        self.ln_1 = nn.LayerNorm(width)
+        self.ln_2 = nn.LayerNorm(width)
+        self.mlp = nn.Sequential()
+        self.mlp.add_module('c_fc', nn.Linear(width, mlp))
+        self.mlp.add_module('gelu', QuickGELU())
+        self.mlp.add_module('c_proj', nn.Linear(mlp, width))
+
+    def forward(self, x):
+        h = self.ln_1(x)
+        x = x + self.attn(h, h, h, need_weights=False)[0]
+        return x + self.mlp(self.ln_2(x))
+
+
+class QuickGELU(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class StandinTransformer(nn.Module):
+    def __init__(self, width, layers, heads, mlp):
+        super().__init__()
+        self.resblocks = nn.Sequential(*[StandinBlock(width, heads, mlp) for _ in range(layers)])
+
+    def forward(self, x):
+        return self.resblocks(x)
+
+
+class StandinVisual(nn.Module):
+    def __init__(self, image, patch, width, layers, heads, mlp, embed):
+        super().__init__()
+        self.patch_size = patch
+        self.grid = image // patch
+        self.conv1 = nn.Conv2d(3, width, patch, patch, bias=False)
+        self.class_embedding = nn.Parameter(torch.zeros(width))
+        self.positional_embedding = nn.Parameter(torch.zeros(self.grid ** 2 + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.transformer = StandinTransformer(width, layers, heads, mlp)
+        self.ln_post = nn.LayerNorm(width)
+        self.proj = nn.Parameter(torch.zeros(width, embed))
+
+    def interpolate_positional_embedding(self, size):
+        from oadp_amd.clip.model import VisionTransformer
+        return VisionTransformer.interpolate_positional_embedding(self, size)
+
+    def forward(self, x):
+        x = self.conv1(x)
+        x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+        cls = self.class_embedding.expand(x.shape[0], 1, -1)
+        x = torch.cat([cls, x], dim=1) + self.positional_embedding
+        x = self.ln_pre(x).permute(1, 0, 2)
+        x = self.transformer(x).permute(1, 0, 2)
+        return self.ln_post(x[:, 0, :]) @ self.proj
+
+
+class StandinCLIP(nn.Module):
+    def __init__(self, **arch):
+        super().__init__()
+        self.visual = StandinVisual(**arch)
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+
+def standin_from_state_dict(sd, arch) -> StandinCLIP:
+    m = StandinCLIP(image=arch['image_size'], patch=arch['patch_size'], width=arch['width'],
+                    layers=arch['layers'], heads=arch['heads'], mlp=arch['mlp_dim'],
+                    embed=arch['embed_dim'])
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+# ---------------------------------------------------------------------------- fixtures
+def gen_blocks(blocks_mod):
+    ds = blocks_mod.Dataset.__new__(blocks_mod.Dataset)
+    ds._r, ds._s, ds._rescale = 224, 112, 1.5
+    ds.transforms = types.SimpleNamespace(transform=tv_transform)
+    lengths = list(range(0, 1500)) + [1700, 2047, 2048, 2049, 3000, 4096, 5000]
+    partition = {str(n): ds._partition(n) for n in lengths}
+    sizes = [(640, 480), (480, 640), (224, 224), (500, 375), (1700, 1134), (223, 500), (225, 224),
+             (336, 337), (1333, 800), (100, 100), (448, 448), (1024, 683)]
+    images = []
+    for (w, h) in sizes:
+        img = PIL.Image.new('RGB', (w, h))
+        tiles = [[im.size[0], im.size[1], scale, x, y] for im, scale, x, y in ds._partitions(img)]
+        bboxes = [list(ds._bbox(scale, x, y)) for _, _, scale, x, y in tiles]
+        batch = ds._preprocess(0, pathlib.Path('x.pth'), img)
+        images.append(dict(size=[w, h], tiles=tiles, bboxes=bboxes,
+                           batch_bboxes=batch.bboxes.tolist(), n_blocks=batch.blocks.shape[0]))
+    (OUT / 'blocks_partition.json').write_text(json.dumps(dict(
+        source='reference oadp/oake/blocks.py Dataset._partition/_partitions/_bbox/_preprocess '
+               '(block_size 224, max_stride 112, rescale 1.5), run under stubs',
+        partition=partition, images=images)))
+    # pixel-level fixture: blocks of one small textured image through the reference _preprocess
+    img = synth_image(300, 260, 7)
+    batch = ds._preprocess(0, pathlib.Path('x.pth'), img)
+    np.savez_compressed(OUT / 'blocks_pixels.npz', image=np.asarray(img),
+                        blocks=batch.blocks.numpy().astype(np.float32), bboxes=batch.bboxes.numpy())
+    print('blocks:', len(partition), 'lengths;', [(i['size'], i['n_blocks']) for i in images])
+
+
+def gen_objects(objects_mod):
+    ds = objects_mod.COCODataset.__new__(objects_mod.COCODataset)
+    ds._grid = 14
+    ds._expand_mode = objects_mod.ExpandMode.ADAPTIVE
+    ds.transforms = types.SimpleNamespace(transform=tv_transform)
+    rng = np.random.default_rng(11)
+    # masks
+    cases = [((10., 20., 60., 90.), (0, 0, 112, 112))]
+    for _ in range(80):
+        ow, oh = int(rng.integers(4, 400)), int(rng.integers(4, 400))
+        if rng.random() < 0.5:
+            oh = ow
+        x1, y1 = rng.uniform(0, ow * 0.8), rng.uniform(0, oh * 0.8)
+        x2, y2 = x1 + rng.uniform(0.5, ow - x1 + 3), y1 + rng.uniform(0.5, oh - y1 + 3)
+        ox, oy = int(rng.integers(0, 50)), int(rng.integers(0, 50))
+        frac = rng.random() < 0.3
+        obj = (ox + (0.5 if frac else 0), oy + (0.25 if frac else 0), ox + ow, oy + oh)
+        cases.append(((float(x1), float(y1), float(x2), float(y2)), obj))
+    masks = [dict(foreground=list(fg), object=list(ob),
+                  mask=ds._mask(fg, ob).reshape(14, 14).to(torch.uint8).tolist()) for fg, ob in cases]
+    # expand + full _preprocess on synthetic proposals
+    expand = []
+    for (w, h), seed in [((640, 480), 1), ((480, 640), 2), ((200, 150), 3), ((1333, 800), 4)]:
+        r = np.random.default_rng(seed)
+        n = 40
+        cx, cy = r.uniform(0, w, n), r.uniform(0, h, n)
+        bw = np.exp(r.uniform(np.log(2), np.log(min(w, h) * 1.2), n))
+        bh = np.exp(r.uniform(np.log(2), np.log(min(w, h) * 1.2), n))
+        x1, y1 = np.clip(cx - bw / 2, 0, w), np.clip(cy - bh / 2, 0, h)
+        x2, y2 = np.clip(cx + bw / 2, 0, w), np.clip(cy + bh / 2, 0, h)
+        score = np.sort(r.uniform(0, 1, n))[::-1]
+        prop = np.stack([x1, y1, x2, y2, score], 1).astype(np.float32)
+        ds._proposals = {0: torch.tensor(prop)}
+        img = synth_image(w, h, seed)
+        batch = ds._preprocess(0, pathlib.Path('x.pth'), img)
+        p_ = BBoxesXYXY(torch.tensor(prop[:, :4]))
+        keep = p_.indices(min_wh=(4, 4))
+        exp = ds._expand(p_[keep], torch.tensor(img.size)).to_tensor()
+        expand.append(dict(image_size=[w, h], proposals=prop.tolist(), keep=keep.tolist(),
+                           expanded=exp.tolist(), bboxes=batch.bboxes.tolist(),
+                           objectness=batch.objectness.tolist(),
+                           masks=batch.masks.reshape(-1, 14, 14).to(torch.uint8).tolist(),
+                           n_objects=int(batch.objects.shape[0])))
+        if seed == 3:
+            np.savez_compressed(OUT / 'objects_pixels.npz', image=np.asarray(img), proposals=prop,
+                                objects=batch.objects.numpy()[:6].astype(np.float32),
+                                expanded=exp.numpy())
+    (OUT / 'objects_masks_expand.json').write_text(json.dumps(dict(
+        source='reference oadp/oake/objects.py COCODataset._mask/_expand/_preprocess (grid 14, ADAPTIVE) '
+               'run under stubs; todd.BBoxes* semantics are INFERRED (tools/gen_golden.py), so `expanded` '
+               'is pinned only up to that inference',
+        masks=masks, expand=expand)))
+    print('objects:', len(masks), 'mask cases;', [e['n_objects'] for e in expand], 'objects per image')
+
+
+def gen_hooks(objects_mod):
+    import clip
+    import clip.model
+    from oadp_amd.weights import synthetic_images, synthetic_state_dict
+    arch = dict(image_size=224, patch_size=32, width=128, layers=3, heads=2, mlp_dim=512, embed_dim=64)
+    sd = synthetic_state_dict(**arch, seed=5)
+    # plain encode (no hooks): stand-in forward
+    standin = standin_from_state_dict(sd, arch)
+    x = synthetic_images(3, seed=41)
+    with torch.no_grad():
+        plain = standin.visual(x)
+    # reference surgery + hooks
+    clip.load_default = lambda *a: (standin_from_state_dict(sd, arch), None)
+    clip.model.ResidualAttentionBlock = StandinBlock
+    with torch.no_grad():
+        model, _ = objects_mod.Validator._build_model()
+        v = model.visual
+        assert v.grid == 14 and tuple(v.conv1.stride) == (16, 16) and tuple(v.conv1.padding) == (15, 15)
+        g = torch.Generator().manual_seed(3)
+        masks = (torch.rand(3, 1, 14, 14, generator=g) > 0.45).float()
+        masks[1] = 0
+        out = model.visual(x, masks.clone())
+        out_all_fg = model.visual(x, torch.zeros(3, 1, 14, 14))
+    np.savez_compressed(OUT / 'hooks_tiny.npz', arch=json.dumps(arch), seed=5, image_seed=41,
+                        masks=masks.numpy(), pos=v.positional_embedding.detach().numpy(),
+                        plain=plain.numpy(), objects=out.numpy(), objects_all_fg=out_all_fg.numpy())
+    print('hooks: plain', tuple(plain.shape), 'objects', tuple(out.shape),
+          'cos(all-fg, masked) =', torch.cosine_similarity(out, out_all_fg).tolist())
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    install_stubs()
+    load_ref('base')
+    load_ref('globals')
+    blocks = load_ref('blocks')
+    objects = load_ref('objects')
+    gen_blocks(blocks)
+    gen_objects(objects)
+    gen_hooks(objects)
+    import PIL
+    (OUT / 'PROVENANCE.json').write_text(json.dumps(dict(
+        generator='tools/gen_golden.py', reference='/root/reference (LutingWang/OADP @ 2024-10-24)',
+        torch=torch.__version__, numpy=np.__version__, pillow=PIL.__version__), indent=1))
+
+
+if __name__ == '__main__':
+    main()
