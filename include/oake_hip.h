@@ -192,6 +192,8 @@ OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, 
 OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
 /* Attention V-fragment path: 0 = 16-bit LDS gathers, 1 = ds_read_b64_tr_b16 transpose reads. */
 OAKE_API int oake_debug_set_attention_variant(int use_tr);
+/* GEMM tile configuration: -1 = automatic per shape, 0..3 = forced (see csrc/gemm.hip). */
+OAKE_API int oake_debug_set_gemm_variant(int variant);
 
 #ifdef __cplusplus
 }

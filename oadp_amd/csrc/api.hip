@@ -23,6 +23,7 @@
 
 namespace oake {
 extern int g_attention_use_tr;
+extern int g_gemm_variant;
 }
 
 using namespace oake;
@@ -654,6 +655,11 @@ int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads
 
 int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
   return dbg(launch_tr_read_probe(d_in, d_out, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_set_gemm_variant(int variant) {
+  oake::g_gemm_variant = variant;
+  return OAKE_OK;
 }
 
 int oake_debug_set_attention_variant(int use_tr) {

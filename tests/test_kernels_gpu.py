@@ -24,6 +24,21 @@ def _stream():
 @pytest.mark.parametrize('m,n,k', [(128, 128, 64), (256, 384, 128), (1350, 768, 768),
                                    (50, 2304, 768), (77, 132, 3072), (12800, 768, 3072)])
 def test_gemm(lib, cuda, dtype, m, n, k):
+    _gemm_case(lib, cuda, dtype, m, n, k)
+
+
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 132, 3072), (12800, 768, 128)])
+def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
+    """Every tile configuration (csrc/gemm.hip) on ragged M/N edges."""
+    lib.oake_debug_set_gemm_variant(variant)
+    try:
+        _gemm_case(lib, cuda, torch.float16, m, n, k)
+    finally:
+        lib.oake_debug_set_gemm_variant(-1)
+
+
+def _gemm_case(lib, cuda, dtype, m, n, k):
     g = torch.Generator(device='cpu').manual_seed(m * 7 + n * 3 + k)
     a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
     w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(dtype).to(cuda)
