@@ -1,0 +1,5 @@
+_base_ = ['base.py']
+_OUT = 'data/coco/oake/globals'
+train = dict(dataloader=dict(dataset=dict(output_dir=f'{_OUT}/train2017')))
+val = dict(dataloader=dict(dataset=dict(output_dir=f'{_OUT}/val2017')))
+log = dict(interval=50)

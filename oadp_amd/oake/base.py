@@ -1,0 +1,247 @@
+"""Shared dataset / run loop of the three OAKE modes.
+
+Reference: oadp/oake/base.py (BaseDataset :28-63, parse_args :66-72, BaseValidator :75-152).
+``torchvision.datasets.CocoDetection`` and ``todd.utils.Validator`` are not dependencies: the COCO
+annotation JSON is read directly (same ``ids = sorted(image ids)`` order and RGB loading), and the
+run loop is ours: iterate the sampler-sharded dataset, skip ``None`` (already extracted), gather
+crops of many images into one encoder batch, scatter per-image results to ``.pth`` files.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import time
+from abc import ABC, abstractmethod
+from typing import Any, Generic, Iterable, Protocol, TypeVar
+
+import PIL.Image
+import torch
+import torch.distributed
+import torch.utils.data
+import torch.utils.data.distributed
+
+from ..config import Config, parse_override
+from ..store import Store, get_local_rank, get_rank, get_world_size
+
+
+class Batch(Protocol):
+
+    @property
+    def output(self) -> pathlib.Path:
+        ...
+
+
+T = TypeVar('T', bound=Batch)
+
+
+class CocoImages:
+    """The slice of pycocotools' COCO + torchvision CocoDetection that OAKE uses."""
+
+    def __init__(self, root: str, annFile: str) -> None:
+        self.root = root
+        with open(annFile) as f:
+            data = json.load(f)
+        self.imgs = {img['id']: img for img in data['images']}  # annotation-file order
+        self.ids = list(sorted(self.imgs.keys()))
+
+    def loadImgs(self, ids: Iterable[int]) -> list[dict]:
+        return [self.imgs[i] for i in ids]
+
+
+class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
+
+    def __init__(self, root: str, annFile: str, *, auto_fix: bool = False, output_dir: str,
+                 transform=None, **kwargs) -> None:
+        self.coco = CocoImages(root, annFile)
+        self.root = root
+        self.ids = self.coco.ids
+        self.transform = transform
+        self._auto_fix = auto_fix
+        self._output_dir = pathlib.Path(output_dir)
+        self._output_dir.mkdir(parents=True, exist_ok=True)
+
+    @property
+    def transforms(self):
+        # torchvision's StandardTransform: ``self.transforms.transform(image)``
+        class _T:
+            transform = staticmethod(self.transform)
+        return _T
+
+    def __len__(self) -> int:
+        return len(self.ids)
+
+    def _load_image(self, id_: int) -> PIL.Image.Image:
+        path = self.coco.loadImgs([id_])[0]['file_name']
+        return PIL.Image.open(os.path.join(self.root, path)).convert('RGB')
+
+    def __getitem__(self, index: int) -> T | None:
+        # reference oadp/oake/base.py:42-54 (resume by skipping; auto_fix re-verifies the file)
+        id_ = self.ids[index]
+        output = self._output_dir / f'{id_:012d}.pth'
+        if output.exists():
+            if not self._auto_fix:
+                return None
+            try:
+                torch.load(output, 'cpu')
+                return None
+            except Exception:
+                print(f'Fixing {output}', flush=True)
+        image = self._load_image(id_)
+        return self._preprocess(id_, output, image)
+
+    @abstractmethod
+    def _preprocess(self, id_: int, output: pathlib.Path, image: PIL.Image.Image) -> T:
+        pass
+
+
+def parse_args(argv: list[str] | None = None) -> argparse.Namespace:
+    parser = argparse.ArgumentParser(description='OAKE feature extraction')
+    parser.add_argument('name', type=str)
+    parser.add_argument('config', type=Config.load)
+    parser.add_argument('--override', nargs='*')
+    return parser.parse_args(argv)
+
+
+def atomic_save(obj: Any, path: pathlib.Path) -> None:
+    """torch.save via tmp + rename: same visible contract as oadp/oake/base.py:112, but a killed
+    run cannot leave a truncated file (what ``auto_fix`` exists to repair)."""
+    tmp = path.with_name(path.name + f'.tmp{os.getpid()}')
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
+class Counters:
+    """[images, crops, seconds, bytes] — the only thing exchanged between ranks."""
+
+    def __init__(self) -> None:
+        self.images = 0
+        self.crops = 0
+        self.seconds = 0.0
+        self.bytes = 0
+
+    def tensor(self, device) -> torch.Tensor:
+        return torch.tensor([self.images, self.crops, self.seconds, self.bytes],
+                            dtype=torch.float64, device=device)
+
+
+def gather_counters(counters: Counters, device) -> list[list[float]]:
+    """Rank-0 throughput report: one all_gather of 4 x f64 per rank (RCCL on GPU, gloo on CPU)."""
+    t = counters.tensor(device)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        out = [torch.zeros_like(t) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(out, t)
+        return [o.tolist() for o in out]
+    return [t.tolist()]
+
+
+class BaseValidator(ABC, Generic[T]):
+
+    def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
+                 batch_size: int = 256, device: torch.device | str | None = None,
+                 **kwargs) -> None:
+        self.name = name
+        self._model = model
+        self._log_interval = (log or {}).get('interval', 50)
+        self._batch_size = batch_size
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if Store.CUDA else 'cpu'
+        self._device = torch.device(device)
+        self.counters = Counters()
+        self._dataloader = self._build_dataloader(Config(dataloader))
+
+    # -- reference surface ----------------------------------------------------------------------
+    def _build_dataloader(self, config: Config) -> torch.utils.data.DataLoader:
+        # reference oadp/oake/base.py:78-89
+        config = Config(config)
+        if Store.DRY_RUN:
+            config['num_workers'] = 0
+        world = get_world_size()
+        if world > 1:
+            config['sampler'] = torch.utils.data.distributed.DistributedSampler(
+                config['dataset'], num_replicas=world, rank=get_rank(), shuffle=False)
+        return torch.utils.data.DataLoader(batch_size=None, **config)
+
+    @classmethod
+    @abstractmethod
+    def _build_model(cls):
+        pass
+
+    @abstractmethod
+    def _encode(self, batches: list[T]) -> list[Any]:
+        """Encode the crops of several images in one pass; one result object per image."""
+
+    def _n_crops(self, batch: T) -> int:
+        return 1
+
+    def _flush(self, pending: list[T]) -> None:
+        if not pending:
+            return
+        results = self._encode(pending)
+        for batch, result in zip(pending, results):
+            atomic_save(result, batch.output)
+            self.counters.images += 1
+            self.counters.bytes += batch.output.stat().st_size
+        pending.clear()
+
+    def run(self) -> Counters:
+        t0 = time.perf_counter()
+        pending: list[T] = []
+        crops = 0
+        for i, batch in enumerate(self._dataloader):
+            if batch is None:  # reference _control_run_iter: CONTINUE on None (base.py:96-104)
+                continue
+            pending.append(batch)
+            crops += self._n_crops(batch)
+            if crops >= self._batch_size:
+                self.counters.crops += crops
+                self._flush(pending)
+                crops = 0
+            if (i + 1) % self._log_interval == 0 and get_rank() == 0:
+                print(f'[{self.name}] iter {i + 1}/{len(self._dataloader)} '
+                      f'images {self.counters.images} crops {self.counters.crops}', flush=True)
+        self.counters.crops += crops
+        self._flush(pending)
+        if self._device.type == 'cuda':
+            torch.cuda.synchronize(self._device)
+        self.counters.seconds += time.perf_counter() - t0
+        return self.counters
+
+    @classmethod
+    def main(cls, argv: list[str] | None = None) -> None:
+        # reference oadp/oake/base.py:115-152
+        args = parse_args(argv)
+        config: Config = args.config
+        override = parse_override(args.override)
+        if override is not None:
+            config.override(override)
+
+        distributed = get_world_size() > 1
+        if Store.CUDA:
+            torch.cuda.set_device(get_local_rank() % torch.cuda.device_count())
+        if distributed:
+            torch.distributed.init_process_group(backend='nccl' if Store.CUDA else 'gloo')
+
+        model, preprocess = cls._build_model()
+
+        train = config.pop('train')
+        val = config.pop('val')
+        train.dataloader.dataset.transform = preprocess
+        val.dataloader.dataset.transform = preprocess
+
+        totals = []
+        for split in (val, train):  # val first, then train — as the reference
+            validator = cls(args.name, model, **split, **config)
+            validator.run()
+            totals.append(gather_counters(validator.counters, validator._device))
+        if get_rank() == 0:
+            for split_name, per_rank in zip(('val', 'train'), totals):
+                images = sum(r[0] for r in per_rank)
+                crops = sum(r[1] for r in per_rank)
+                secs = max(r[2] for r in per_rank)
+                print(f'[{args.name}] {split_name}: {int(images)} images, {int(crops)} crops, '
+                      f'{secs:.1f} s, {images / max(secs, 1e-9):.1f} images/s over '
+                      f'{len(per_rank)} rank(s)', flush=True)
+        if distributed:
+            torch.distributed.destroy_process_group()

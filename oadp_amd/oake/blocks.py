@@ -1,0 +1,107 @@
+"""``oadp.oake.blocks``: image pyramid tiled into 224x224 blocks (+ the whole-image crop) ->
+dict(embeddings [K,512] f16, bboxes [K,4] f16).  Reference: oadp/oake/blocks.py."""
+from __future__ import annotations
+
+import itertools
+import pathlib
+from typing import Generator, NamedTuple
+
+import PIL.Image
+import torch
+
+from .. import clip
+from ..config import Config
+from .base import BaseDataset, BaseValidator
+
+
+class Batch(NamedTuple):
+    output: pathlib.Path
+    blocks: torch.Tensor
+    bboxes: torch.Tensor
+
+
+class Dataset(BaseDataset[Batch]):
+
+    def __init__(self, *args, block_size: int = 224, max_stride: int = 112, rescale: float = 1.5,
+                 **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self._r = block_size
+        self._s = max_stride
+        self._rescale = rescale
+
+    def _partition(self, length: int) -> list[int]:
+        """Tile origins along one axis (reference blocks.py:40-52): n = ceil((len - r) / s) steps of
+        near-equal integer size, the first ``rem`` steps one pixel longer."""
+        if length < self._r:
+            return []
+        if length == self._r:
+            return [0]
+        n = (length - self._r - 1) // self._s + 1
+        q, rem = divmod(length - self._r, n)
+        origins = [0]
+        for i in range(n):
+            origins.append(origins[-1] + q + (1 if i < rem else 0))
+        return origins
+
+    def _partitions(self, image: PIL.Image.Image,
+                    ) -> Generator[tuple[PIL.Image.Image, float, int, int], None, None]:
+        """Pyramid walk (reference blocks.py:54-77): x-major product of the two partitions per
+        level; next level = PIL bicubic resize to (int(w / 1.5), int(h / 1.5))."""
+        scale = 1.0
+        while True:
+            w, h = image.size
+            tiles = list(itertools.product(self._partition(w), self._partition(h)))
+            if not tiles:
+                return
+            for x, y in tiles:
+                yield image, scale, x, y
+            image = image.resize((int(w / self._rescale), int(h / self._rescale)))
+            scale *= self._rescale
+
+    def _block(self, image: PIL.Image.Image, x: int, y: int) -> torch.Tensor:
+        return self.transforms.transform(image.crop((x, y, x + self._r, y + self._r)))
+
+    def _bbox(self, scale: float, x: int, y: int) -> tuple[float, float, float, float]:
+        x1, y1, r = x * scale, y * scale, self._r * scale
+        return (x1, y1, x1 + r, y1 + r)
+
+    def _preprocess(self, id_: int, output: pathlib.Path, image: PIL.Image.Image) -> Batch:
+        # reference blocks.py:89-109.  Block 0 = whole image; its bbox is (x, y, side, side) —
+        # NOT xyxy — a quirk of the reference that the consumer inherits, reproduced verbatim.
+        w, h = image.size
+        blocks = [self.transforms.transform(image)]
+        bboxes: list[tuple] = [((w - h) / 2, 0, h, h) if w > h else (0, (h - w) / 2, w, w)]
+        for level, scale, x, y in self._partitions(image):
+            blocks.append(self._block(level, x, y))
+            bboxes.append(self._bbox(scale, x, y))
+        return Batch(output, torch.stack(blocks), torch.tensor(bboxes))
+
+
+class Validator(BaseValidator[Batch]):
+
+    def _build_dataloader(self, config: Config):
+        config = Config(config)
+        config['dataset'] = Dataset(**config['dataset'])
+        return super()._build_dataloader(config)
+
+    @classmethod
+    def _build_model(cls):
+        return clip.load_default(False)
+
+    def _n_crops(self, batch: Batch) -> int:
+        return batch.blocks.shape[0]
+
+    def _encode(self, batches: list[Batch]) -> list[dict]:
+        # reference _run_iter (blocks.py:125-135), crops of several images in one encoder pass
+        blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
+        emb = self._model.encode_image(blocks, normalize=True, out_dtype=torch.float16).cpu()
+        out, i = [], 0
+        for b in batches:
+            k = b.blocks.shape[0]
+            out.append(dict(embeddings=emb[i:i + k].clone(), bboxes=b.bboxes.half()))
+            i += k
+        return out
+
+
+if __name__ == '__main__':
+    Validator.main()

@@ -1,0 +1,186 @@
+"""``oadp.oake.objects``: proposal-driven square crops + 14x14 background masks, encoded with the
+object-aware two-stream ViT -> dict(embeddings [N,512], bboxes [N,4], objectness [N,1]) f16.
+Reference: oadp/oake/objects.py (COCODataset :43-195, Hooks :198-266, Validator :269-338).
+
+The reference gets its box arithmetic from ``todd.BBoxes*`` (un-vendored).  Boxes here are plain
+[n,4] float32 tensors (x1,y1,x2,y2); semantics per SURVEY.md §8c: wh = rb - lt, ``indices(min_wh)``
+keeps w >= 4 and h >= 4 (>= vs > is unknown upstream — unpinned).
+"""
+from __future__ import annotations
+
+import enum
+import math
+import os
+import pathlib
+import pickle
+from typing import NamedTuple
+
+import PIL.Image
+import torch
+import torch.nn.functional as F
+
+from .. import clip
+from ..config import Config
+from ..store import Store
+from .base import BaseDataset, BaseValidator
+
+
+class Batch(NamedTuple):
+    output: pathlib.Path
+    objects: torch.Tensor
+    bboxes: torch.Tensor
+    objectness: torch.Tensor
+    masks: torch.Tensor
+
+
+class ExpandMode(enum.Enum):
+    RECTANGLE = enum.auto()
+    LONGEST_EDGE = enum.auto()
+    CONSTANT = enum.auto()
+    ADAPTIVE = enum.auto()
+
+
+def indices_min_wh(boxes: torch.Tensor, min_wh: tuple[float, float]) -> torch.Tensor:
+    wh = boxes[:, 2:] - boxes[:, :2]
+    return (wh[:, 0] >= min_wh[0]) & (wh[:, 1] >= min_wh[1])
+
+
+class COCODataset(BaseDataset[Batch]):
+
+    def __init__(self, *args, grid: int, expand_mode: str = 'ADAPTIVE', proposal_file: str,
+                 proposal_sorted: bool, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self._grid = grid
+        self._expand_mode = ExpandMode[expand_mode]
+        with open(proposal_file, 'rb') as f:
+            proposals = pickle.load(f)
+        # reference objects.py:68-74: proposals align with sorted ids, or annotation-file order
+        ids = self.ids if proposal_sorted else list(self.coco.imgs.keys())
+        self._proposals = {id_: torch.as_tensor(p, dtype=torch.float32).reshape(-1, 5)
+                           for id_, p in zip(ids, proposals)}
+
+    def _expand(self, bboxes: torch.Tensor, image_wh: torch.Tensor) -> torch.Tensor:
+        """Square context boxes (reference objects.py:76-114).  ADAPTIVE: side = sqrt(8 * area),
+        centred on the proposal, then shifted back inside the image where it sticks out; a box
+        larger than the image stays centred."""
+        wh = bboxes[:, 2:] - bboxes[:, :2]
+        if self._expand_mode is ExpandMode.ADAPTIVE:
+            length = torch.sqrt(wh[:, 0] * wh[:, 1] * 8).unsqueeze(1)
+        elif self._expand_mode is ExpandMode.CONSTANT:
+            length = torch.full((bboxes.shape[0], 1), 224.0)
+        elif self._expand_mode is ExpandMode.LONGEST_EDGE:
+            length = wh.max(dim=1, keepdim=True).values
+        else:
+            raise ValueError(self._expand_mode)
+        center = (bboxes[:, :2] + bboxes[:, 2:]) / 2
+        lt = center - length / 2
+        rb = center + length / 2
+        image_wh = image_wh.to(torch.float32)
+        offset = torch.zeros_like(lt)
+        offset = torch.where(lt >= 0, offset, -lt)
+        offset = torch.where(rb <= image_wh, offset, image_wh - rb)
+        offset = torch.where((rb - lt) <= image_wh, offset, torch.tensor(0.0))
+        return torch.cat([lt + offset, rb + offset], dim=1)
+
+    def _object(self, image: PIL.Image.Image, bbox) -> torch.Tensor:
+        # PIL rounds each coordinate (banker's rounding) and zero-pads outside the image
+        return self.transforms.transform(image.crop(tuple(float(v) for v in bbox)))
+
+    def _mask(self, foreground, object) -> torch.Tensor:
+        """[1,1,grid,grid]: 0 on the proposal, 1 on background (reference objects.py:129-155):
+        a (y2-y1) x (x2-x1) pixel mask resampled 'nearest' to grid x grid."""
+        x = torch.arange(object[2] - object[0])
+        y = torch.arange(object[3] - object[1])
+        inside_x = (foreground[0] <= x) & (x <= foreground[2])
+        inside_y = (foreground[1] <= y) & (y <= foreground[3])
+        mask = ~(inside_y[:, None] & inside_x[None, :])
+        return F.interpolate(mask[None, None].float(), size=(self._grid, self._grid), mode='nearest')
+
+    def _preprocess(self, id_: int, output: pathlib.Path, image: PIL.Image.Image) -> Batch:
+        prop = self._proposals[id_]
+        proposals, objectness = prop[:, :4], prop[:, 4:]
+        keep = indices_min_wh(proposals, (4, 4))
+        if Store.DRY_RUN:
+            keep[5:] = False
+        proposals, objectness = proposals[keep], objectness[keep]
+
+        bboxes = self._expand(proposals, torch.tensor(image.size))
+        foregrounds = proposals - torch.cat([bboxes[:, :2], bboxes[:, :2]], dim=1)
+
+        objects, masks = [], []
+        for fg, box in zip(foregrounds.tolist(), bboxes.tolist()):
+            objects.append(self._object(image, box))
+            masks.append(self._mask(tuple(fg), tuple(box)))
+        if not objects:
+            s = self.transform.n_px if hasattr(self.transform, 'n_px') else 224
+            return Batch(output, torch.zeros(0, 3, s, s), proposals, objectness,
+                         torch.zeros(0, 1, self._grid, self._grid))
+        return Batch(output, torch.stack(objects), proposals, objectness, torch.cat(masks))
+
+
+class LVISDataset(COCODataset):
+
+    def _load_image(self, id_: int) -> PIL.Image.Image:
+        info = self.coco.loadImgs([id_])[0]
+        path = info['coco_url'].replace('http://images.cocodataset.org/', '')
+        return PIL.Image.open(os.path.join(self.root, path)).convert('RGB')
+
+
+DATASETS = dict(COCODataset=COCODataset, LVISDataset=LVISDataset)
+
+
+class Validator(BaseValidator[Batch]):
+
+    def __init__(self, *args, mini_batch_size: int, **kwargs) -> None:
+        self._mini_batch_size = mini_batch_size
+        super().__init__(*args, **kwargs)
+
+    def _build_dataloader(self, config: Config):
+        config = Config(config)
+        ds = dict(config['dataset'])
+        cls = DATASETS[ds.pop('type')]
+        ds.setdefault('grid', self._model.visual.grid)
+        config['dataset'] = cls(**ds)
+        return super()._build_dataloader(config)
+
+    @classmethod
+    def _build_model(cls, upsample: int = 2):
+        """The reference's surgery (objects.py:285-314) on our model facade: interpolated positional
+        embedding, conv1 stride // upsample, padding (patch-1)//2, and the object-token stream
+        (implemented in the HIP library instead of forward hooks)."""
+        model, preprocess = clip.load_default(False)
+        visual = model.visual
+        visual.positional_embedding = visual.interpolate_positional_embedding((visual.grid * 2,) * 2)
+        visual.grid *= upsample
+        conv1 = visual.conv1
+        conv1.stride = tuple(s // upsample for s in conv1.stride)
+        conv1.padding = ((visual.patch_size - 1) // 2,) * 2
+        visual.object_stream = True
+        return model, preprocess
+
+    def _n_crops(self, batch: Batch) -> int:
+        return batch.objects.shape[0]
+
+    def _encode(self, batches: list[Batch]) -> list[dict]:
+        # reference _run_iter (objects.py:316-338): mini-batches of `mini_batch_size` crops through
+        # model.visual(objects, masks), normalise, cat, .half() x3
+        objects = torch.cat([b.objects for b in batches])
+        masks = torch.cat([b.masks for b in batches])
+        embs = []
+        for i in range(math.ceil(objects.shape[0] / self._mini_batch_size)):
+            sl = slice(i * self._mini_batch_size, (i + 1) * self._mini_batch_size)
+            o = objects[sl].to(self._device, non_blocking=True)
+            m = masks[sl].to(self._device, non_blocking=True)
+            embs.append(self._model.visual(o, m, normalize=True, out_dtype=torch.float16).cpu())
+        emb = torch.cat(embs) if embs else torch.zeros(0, 512, dtype=torch.float16)
+        out, i = [], 0
+        for b in batches:
+            n = b.objects.shape[0]
+            out.append(dict(embeddings=emb[i:i + n].clone(), bboxes=b.bboxes.half(),
+                            objectness=b.objectness.half()))
+            i += n
+        return out
+
+
+if __name__ == '__main__':
+    Validator.main()

@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/oake_hip.h declares
+(no compute calls here — those are the -m gpu tests)."""
+import ctypes as C
+import pathlib
+import re
+import subprocess
+
+from oadp_amd import _lib
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+HEADER = ROOT / 'include' / 'oake_hip.h'
+
+
+def _declared():
+    text = HEADER.read_text()
+    return sorted(set(re.findall(r'OAKE_API[^;]*?\b(oake_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    names = _declared()
+    assert len(names) >= 20
+    out = subprocess.run(['nm', '-D', '--defined-only', str(_lib.LIB_PATH)], capture_output=True,
+                         text=True, check=True).stdout
+    exported = set(re.findall(r' T (oake_[a-z0-9_]+)', out))
+    assert set(names) <= exported, set(names) - exported
+    # and the Python binding covers exactly the header
+    assert set(_lib.SIGNATURES) == set(names)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_abi_version_and_default_config(lib):
+    assert lib.oake_abi_version() == _lib.ABI_VERSION
+    cfg = _lib.OakeConfig()
+    lib.oake_default_config(C.byref(cfg))
+    assert (cfg.image_size, cfg.patch_size, cfg.stride, cfg.padding) == (224, 32, 32, 0)
+    assert (cfg.width, cfg.layers, cfg.heads, cfg.mlp_dim, cfg.embed_dim) == (768, 12, 12, 3072, 512)
+    assert cfg.compute_dtype == _lib.OAKE_F16 and cfg.max_batch == 256
+    assert C.sizeof(_lib.OakeConfig) == 48
+
+
+def test_create_rejects_bad_config_without_gpu(lib):
+    cfg = _lib.OakeConfig()
+    lib.oake_default_config(C.byref(cfg))
+    cfg.width = 100  # not heads * 64
+    h = C.c_void_p()
+    assert lib.oake_create(C.byref(cfg), 0, C.byref(h)) == 1  # OAKE_ERR_INVALID, before any HIP call
+    assert b'width' in lib.oake_last_error(None)
+
+
+def test_no_cpu_fallback_in_product():
+    """The product path never imports the oracle and refuses CPU tensors."""
+    import torch
+    from oadp_amd import clip
+    from oadp_amd.weights import synthetic_state_dict
+    for p in (ROOT / 'oadp_amd').rglob('*.py'):
+        assert 'oracle' not in p.read_text().replace('oracle/', ''), p
+    model, _ = clip.load(synthetic_state_dict(width=128, layers=1, heads=2, mlp_dim=256, embed_dim=64))
+    try:
+        model.encode_image(torch.zeros(1, 3, 224, 224))
+    except RuntimeError as e:
+        assert 'no CPU fallback' in str(e)
+    else:
+        raise AssertionError('CPU tensor was accepted')

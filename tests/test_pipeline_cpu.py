@@ -1,0 +1,167 @@
+"""Host pipeline on CPU: dataset -> batched encode -> per-image .pth files,
+resume / auto_fix, sampler sharding and the counters gather (gloo, world_size 2).
+The encoder is replaced by an oracle-backed test double (tests/_synth.py) — the product's own
+encoder only runs on the GPU (tests/test_oake_gpu.py)."""
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oadp_amd.config import Config, parse_override
+from oadp_amd.oake import blocks, globals as globals_, objects
+
+from . import _synth
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+SIZES = [(300, 260), (224, 224), (500, 375), (250, 340), (100, 90)]
+
+
+@pytest.fixture()
+def coco(tmp_path):
+    return _synth.make_coco(tmp_path / 'coco', SIZES)
+
+
+def _dl(coco, out, **extra):
+    return Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(out),
+                               transform=_synth.preprocess(), **extra), num_workers=0)
+
+
+def test_globals_file_contract_and_resume(coco, tmp_path):
+    out = tmp_path / 'globals'
+    v = globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, out), batch_size=2,
+                           log=dict(interval=2), device='cpu')
+    c = v.run()
+    assert c.images == len(SIZES) and c.crops == len(SIZES)
+    files = sorted(p.name for p in out.iterdir())
+    assert files == [f'{i:012d}.pth' for i in coco['ids']]          # <image_id:012d>.pth
+    t = torch.load(out / files[0], 'cpu')
+    assert isinstance(t, torch.Tensor) and t.dtype == torch.float16 and t.shape == (64,)
+    assert abs(float(t.float().norm()) - 1.0) < 2e-3                 # normalised before .half()
+    assert t.squeeze(0).shape == (64,)                               # LoadCLIPFeatures: .squeeze(0)
+    # resume: every file exists -> nothing recomputed
+    v2 = globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, out), device='cpu')
+    assert v2.run().images == 0
+    # auto_fix: a truncated file is recomputed, intact ones are kept
+    (out / files[1]).write_bytes(b'broken')
+    v3 = globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, out, auto_fix=True), device='cpu')
+    assert v3.run().images == 1
+    assert torch.equal(torch.load(out / files[1], 'cpu'),
+                       torch.load(out / files[1], 'cpu'))
+
+
+def test_blocks_file_contract(coco, tmp_path):
+    out = tmp_path / 'blocks'
+    v = blocks.Validator('b', _synth.OracleModel(), dataloader=_dl(coco, out), batch_size=8, device='cpu')
+    v.run()
+    import json
+    sizes = {im['id']: (im['width'], im['height']) for im in json.load(open(coco['annFile']))['images']}
+    from oracle import crops_ref
+    for id_ in coco['ids']:
+        d = torch.load(out / f'{id_:012d}.pth', 'cpu')
+        assert set(d) == {'embeddings', 'bboxes'}
+        w, h = sizes[id_]
+        exp = torch.from_numpy(crops_ref.all_block_bboxes(w, h)).half()
+        assert d['embeddings'].dtype == torch.float16 and d['bboxes'].dtype == torch.float16
+        assert d['embeddings'].shape == (exp.shape[0], 64)
+        assert torch.equal(d['bboxes'], exp)                        # row 0 = whole-image crop
+    # an image smaller than one block still yields block 0
+    small = [i for i, s in sizes.items() if s == (100, 90)][0]
+    assert torch.load(out / f'{small:012d}.pth', 'cpu')['embeddings'].shape[0] == 1
+
+
+def test_objects_file_contract(coco, tmp_path, monkeypatch):
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    out = tmp_path / 'objects'
+    model = _synth.OracleModel()
+    model.visual.objects_mode()
+    dl = _dl(coco, out, type='COCODataset', proposal_file=coco['proposal_file'], proposal_sorted=True)
+    v = objects.Validator('o', model, dataloader=dl, mini_batch_size=7, batch_size=16, device='cpu')
+    v.run()
+    import pickle
+    props = pickle.load(open(coco['proposal_file'], 'rb'))
+    for id_, p in zip(coco['ids'], props):
+        d = torch.load(out / f'{id_:012d}.pth', 'cpu')
+        assert set(d) == {'embeddings', 'bboxes', 'objectness'}
+        keep = ((p[:, 2] - p[:, 0]) >= 4) & ((p[:, 3] - p[:, 1]) >= 4)
+        n = int(keep.sum())
+        assert d['embeddings'].shape == (n, 64) and d['bboxes'].shape == (n, 4) and d['objectness'].shape == (n, 1)
+        assert all(t.dtype == torch.float16 for t in d.values())
+        # bboxes are the un-expanded, min_wh-filtered proposals (reference objects.py:183)
+        assert torch.equal(d['bboxes'], torch.from_numpy(p[keep, :4]).half())
+
+
+def test_objects_validator_surgery(monkeypatch):
+    """Validator._build_model applies the reference's geometry surgery to our facade."""
+    monkeypatch.setenv('OAKE_SYNTHETIC_WEIGHTS', '1')
+    import oadp_amd.clip.model as cm
+    from oadp_amd.weights import synthetic_state_dict
+    monkeypatch.setattr(cm, 'load_default', lambda flag=False, **k: cm.load(
+        synthetic_state_dict(**_synth.TINY), squash=flag, **k))
+    monkeypatch.setattr(objects.clip, 'load_default', cm.load_default)
+    model, pre = objects.Validator._build_model()
+    v = model.visual
+    assert v.grid == 14 and v.conv1.stride == (16, 16) and v.conv1.padding == (15, 15)
+    assert v.positional_embedding.shape == (197, 128) and v.object_stream
+
+
+def test_config_loader_and_override():
+    cfg = Config.load(ROOT / 'configs' / 'oake' / 'objects_lvis.py')
+    assert cfg.mini_batch_size == 512 and cfg.log.interval == 5
+    assert cfg.train.dataloader.dataset.type == 'LVISDataset'
+    assert cfg.train.dataloader.dataset.proposal_sorted is True          # inherited from objects_coco
+    assert cfg.val.dataloader.num_workers == 2                            # inherited from base
+    assert cfg.train.dataloader.dataset.output_dir == 'data/lvis_v1/oake/objects/train2017'
+    g = Config.load(ROOT / 'configs' / 'oake' / 'globals.py')
+    assert g.val.dataloader.dataset.output_dir == 'data/coco/oake/globals/val2017'
+    g.override(parse_override(['.train.dataloader.dataset.auto_fix:True', '.log.interval:7']))
+    assert g.train.dataloader.dataset.auto_fix is True and g.log.interval == 7
+
+
+def test_sampler_shards_like_distributed_sampler(coco, tmp_path, monkeypatch):
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    seen = []
+    for rank in (0, 1):
+        monkeypatch.setenv('RANK', str(rank))
+        out = tmp_path / f'g{rank}'
+        v = globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, out), device='cpu')
+        v.run()
+        seen.append(sorted(int(p.stem) for p in out.iterdir()))
+    ids = coco['ids']
+    # DistributedSampler(shuffle=False): rank r takes r, r+W, ... of the sorted ids, padded by wrap
+    assert seen[0] == sorted({ids[i % len(ids)] for i in range(0, 6, 2)})
+    assert seen[1] == sorted({ids[i % len(ids)] for i in range(1, 6, 2)})
+
+
+def test_two_rank_gloo_run(coco, tmp_path):
+    """world_size 2 over gloo: disjoint files, all images covered, counters gathered to rank 0."""
+    out = tmp_path / 'dist'
+    script = tmp_path / 'run2.py'
+    script.write_text(f'''
+import sys, torch, torch.distributed as td
+sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / "tests")!r})
+from tests import _synth
+from oadp_amd.config import Config
+from oadp_amd.oake import globals as g
+from oadp_amd.oake.base import gather_counters
+td.init_process_group('gloo')
+dl = Config(dataset=dict(root={coco["root"]!r}, annFile={coco["annFile"]!r}, output_dir={str(out)!r},
+            transform=_synth.preprocess()), num_workers=0)
+v = g.Validator('g', _synth.OracleModel(), dataloader=dl, device='cpu')
+v.run()
+per_rank = gather_counters(v.counters, 'cpu')
+if td.get_rank() == 0:
+    print('GATHER', len(per_rank), int(sum(r[0] for r in per_rank)))
+td.destroy_process_group()
+''')
+    env = dict(os.environ, PYTHONPATH=str(ROOT))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                        '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port', '29533',
+                        str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # 5 images over 2 ranks: the sampler pads to 6 by wrap-around; the duplicate is either written
+    # twice or skipped by the resume rule, depending on timing
+    assert 'GATHER 2 6' in r.stdout or 'GATHER 2 5' in r.stdout, r.stdout
+    assert sorted(int(p.stem) for p in out.iterdir()) == coco['ids']
