@@ -194,6 +194,8 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
 OAKE_API int oake_debug_set_attention_variant(int use_tr);
 /* GEMM tile configuration: -1 = automatic per shape, 0..3 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
+/* Debug: device buffer of 16*64*4 uint64 receiving per-K-tile cycle stamps, or NULL to disable. */
+OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
 
 #ifdef __cplusplus
 }

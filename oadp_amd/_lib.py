@@ -48,6 +48,7 @@ SIGNATURES = {
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
     'oake_debug_set_attention_variant': (_I, [_I]),
     'oake_debug_set_gemm_variant': (_I, [_I]),
+    'oake_debug_set_gemm_trace': (_I, [_VP]),
 }
 
 _lib = None

@@ -24,6 +24,8 @@
 namespace oake {
 extern int g_attention_use_tr;
 extern int g_gemm_variant;
+extern int g_gemm_krot;
+extern unsigned long long* g_gemm_trace;
 }
 
 using namespace oake;
@@ -658,7 +660,19 @@ int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
 }
 
 int oake_debug_set_gemm_variant(int variant) {
-  oake::g_gemm_variant = variant;
+  // bits 0..7: tile configuration (or -1 = auto); bit 8 set = enable the rotated K walk
+  if (variant < 0) {
+    oake::g_gemm_variant = -1;
+    oake::g_gemm_krot = 0;
+  } else {
+    oake::g_gemm_variant = (variant & 0xff) == 0xff ? -1 : (variant & 0xff);
+    oake::g_gemm_krot = (variant >> 8) & 7;  // bit 8: rotated K walk (v2); bits 9/10: v6 ablations
+  }
+  return OAKE_OK;
+}
+
+int oake_debug_set_gemm_trace(void* d_trace) {
+  oake::g_gemm_trace = reinterpret_cast<unsigned long long*>(d_trace);
   return OAKE_OK;
 }
 
