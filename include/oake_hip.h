@@ -182,6 +182,9 @@ OAKE_API int oake_profile_reset(oake_handle* h);
 /* C[m,n] = A[m,k] * W[n,k]^T + bias[n] (fp32 out).  A, W are 16-bit row-major. */
 OAKE_API int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bias, float* d_c,
                     int m, int n, int k, int dtype16, void* stream);
+/* C16[m,n] = (quick_gelu?)(A * W^T + bias) stored in the 16-bit operand type (n % 8 == 0). */
+OAKE_API int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, void* d_c,
+                      int m, int n, int k, int dtype16, int gelu, void* stream);
 /* y = LayerNorm(x) over last dim `c` (eps 1e-5), x fp32 [rows,c] -> y 16-bit [rows,c]. */
 OAKE_API int oake_debug_layernorm(const float* d_x, const float* d_gamma, const float* d_beta,
                          void* d_y, int rows, int c, int dtype16, void* stream);
@@ -192,9 +195,10 @@ OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, 
 OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
 /* Attention V-fragment path: 0 = 16-bit LDS gathers, 1 = ds_read_b64_tr_b16 transpose reads. */
 OAKE_API int oake_debug_set_attention_variant(int use_tr);
-/* GEMM tile configuration: -1 = automatic per shape, 0..3 = forced (see csrc/gemm.hip). */
+/* GEMM configuration: -1 = automatic per shape, 0..4 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
-/* Debug: device buffer of 16*64*4 uint64 receiving per-K-tile cycle stamps, or NULL to disable. */
+/* Debug: device buffer of 64*2*8*4 uint64 receiving per-tile cycle stamps of the production GEMM
+ * (entry, tile start, epilogue start, epilogue end), or NULL to disable. */
 OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
 
 #ifdef __cplusplus

@@ -24,7 +24,6 @@
 namespace oake {
 extern int g_attention_use_tr;
 extern int g_gemm_variant;
-extern int g_gemm_krot;
 extern unsigned long long* g_gemm_trace;
 }
 
@@ -643,6 +642,14 @@ int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bias, float
   return dbg(launch_gemm(dtype16, EPI_F32_BIAS, a, reinterpret_cast<hipStream_t>(stream)));
 }
 
+int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, void* d_c, int m, int n,
+                      int k, int dtype16, int gelu, void* stream) {
+  GemmArgs a{};
+  a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
+  return dbg(launch_gemm(dtype16, gelu ? EPI_T16_GELU : EPI_T16_BIAS, a,
+                         reinterpret_cast<hipStream_t>(stream)));
+}
+
 int oake_debug_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, void* d_y,
                          int rows, int c, int dtype16, void* stream) {
   return dbg(launch_layernorm(dtype16, d_x, c, d_gamma, d_beta, d_y, rows, c,
@@ -660,14 +667,7 @@ int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
 }
 
 int oake_debug_set_gemm_variant(int variant) {
-  // bits 0..7: tile configuration (or -1 = auto); bit 8 set = enable the rotated K walk
-  if (variant < 0) {
-    oake::g_gemm_variant = -1;
-    oake::g_gemm_krot = 0;
-  } else {
-    oake::g_gemm_variant = (variant & 0xff) == 0xff ? -1 : (variant & 0xff);
-    oake::g_gemm_krot = (variant >> 8) & 7;  // bit 8: rotated K walk (v2); bits 9/10: v6 ablations
-  }
+  oake::g_gemm_variant = variant < 0 ? -1 : variant;
   return OAKE_OK;
 }
 

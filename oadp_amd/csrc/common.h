@@ -74,9 +74,12 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// QuickGELU (OpenAI CLIP): x * sigmoid(1.702 x)
+// QuickGELU (OpenAI CLIP): x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)).
+// v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division: the result is rounded to 16 bits
+// right after, and the c_fc epilogue evaluates this 80 times per lane per tile.
 __device__ __forceinline__ float quick_gelu(float x) {
-  return x / (1.0f + __expf(-1.702f * x));
+  const float e = __builtin_amdgcn_exp2f(x * -2.4554669595930156f);  // 1.702 * log2(e)
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // XCD-aware bijective block remap (guide T1): hardware places block b on XCD b % 8; give each

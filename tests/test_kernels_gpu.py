@@ -27,7 +27,7 @@ def test_gemm(lib, cuda, dtype, m, n, k):
     _gemm_case(lib, cuda, dtype, m, n, k)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 10, 11])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 132, 3072), (12800, 768, 128)])
 def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
     """Every tile configuration (csrc/gemm.hip) on ragged M/N edges."""
@@ -36,6 +36,33 @@ def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
         _gemm_case(lib, cuda, torch.float16, m, n, k)
     finally:
         lib.oake_debug_set_gemm_variant(-1)
+
+
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('gelu', [0, 1])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 136, 512),
+                                   (12800, 3072, 128)])
+def test_gemm_16bit_epilogues(lib, cuda, variant, gelu, dtype, m, n, k):
+    """QKV / c_fc epilogues: bias (+QuickGELU) and the paired-column 16-byte stores."""
+    g = torch.Generator(device='cpu').manual_seed(m + n + k + gelu)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(dtype).to(cuda)
+    bias = torch.randn(n, generator=g).to(cuda)
+    c = torch.full((m, n), float('nan'), dtype=dtype, device=cuda)
+    lib.oake_debug_set_gemm_variant(variant)
+    try:
+        rc = lib.oake_debug_gemm16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k,
+                                   DT[dtype], gelu, _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.oake_debug_set_gemm_variant(-1)
+    ref = a.float() @ w.float().t() + bias
+    if gelu:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
 
 
 def _gemm_case(lib, cuda, dtype, m, n, k):
