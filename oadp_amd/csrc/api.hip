@@ -65,7 +65,7 @@ struct oake_handle {
   float* cls = nullptr;       // [width]
   float* pos = nullptr;       // [tokens, width]
   float *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr;
-  void* proj = nullptr;       // [width, embed] 16-bit
+  void* proj = nullptr;       // [embed, width] 16-bit (visual.proj transposed: GEMM W operand)
   std::vector<LayerW> layers;
   std::map<std::string, bool> loaded;
   float* stage = nullptr;     // fp32 staging for uploads
@@ -76,6 +76,7 @@ struct oake_handle {
   float* x = nullptr;
   void *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr;
   float* y = nullptr;
+  float* e32 = nullptr;       // [B, embed] fp32 head projection
   void *yn = nullptr, *qkv_y = nullptr, *att_y = nullptr, *h_y = nullptr;
 
   // profiler
@@ -226,7 +227,7 @@ void oake_destroy(oake_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
-                  h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y,
+                  h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
                   h->yn, h->qkv_y, h->att_y, h->h_y};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -260,7 +261,8 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
     return bad("patch_size must be a multiple of 8");
   if (c.stride <= 0 || c.padding < 0 || c.image_size + 2 * c.padding < c.patch_size)
     return bad("bad conv1 geometry");
-  if (c.embed_dim % 2 != 0 || c.embed_dim > 1024 || c.embed_dim <= 0) return bad("bad embed_dim");
+  if (c.embed_dim % 4 != 0 || c.embed_dim > 1024 || c.embed_dim <= 0)
+    return bad("embed_dim must be a multiple of 4 and <= 1024");
   if (c.compute_dtype != OAKE_F16 && c.compute_dtype != OAKE_BF16)
     return bad("compute_dtype must be OAKE_F16 or OAKE_BF16");
   if (c.layers <= 0 || c.max_batch <= 0) return bad("layers and max_batch must be positive");
@@ -317,6 +319,7 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   A(&h->att, B * L * C * e16());
   A(&h->hbuf, B * L * F * e16());
   A((void**)&h->y, B * C * 4);
+  A((void**)&h->e32, B * E * 4);
   A(&h->yn, B * C * e16());
   A(&h->qkv_y, B * 3 * C * e16());
   A(&h->att_y, B * C * e16());
@@ -372,7 +375,14 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
   else if (key == "visual.ln_pre.bias") F32(h->lnpre_b, C);
   else if (key == "visual.ln_post.weight") F32(h->lnpost_g, C);
   else if (key == "visual.ln_post.bias") F32(h->lnpost_b, C);
-  else if (key == "visual.proj") W16(h->proj, C * E);
+  else if (key == "visual.proj") {
+    // state_dict layout is [width, embed] (x @ proj); the GEMM wants W[N = embed][K = width]
+    if ((rc = expect(C * E)) != OAKE_OK) return rc;
+    std::vector<float> t(C * E);
+    for (size_t cc = 0; cc < C; ++cc)
+      for (size_t ee = 0; ee < E; ++ee) t[ee * C + cc] = data[cc * E + ee];
+    if ((rc = upload_16(h, h->proj, t.data(), C * E)) != OAKE_OK) return rc;
+  }
   else {
     // visual.transformer.resblocks.<l>.<leaf>
     const std::string prefix = "visual.transformer.resblocks.";
@@ -454,6 +464,20 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   return OAKE_OK;
 }
 
+// ln_post over `nb` rows (x + i*row_stride) -> @ proj -> optional L2 normalise -> out
+int head(oake_handle* h, hipStream_t s, const float* x, long row_stride, void* outp, int out_dtype,
+         int normalize, int nb) {
+  const int C = h->cfg.width, E = h->cfg.embed_dim;
+  RUN(h, s, "head_ln_post", 0.0, (double)nb * C * 6,
+      launch_layernorm(h->dt16, x, row_stride, h->lnpost_g, h->lnpost_b, h->yn, nb, C, s));
+  int rc;
+  if ((rc = gemm(h, s, "gemm_head_proj", EPI_F32_BIAS, h->yn, h->proj, nullptr, h->e32, nb, E, C, E)))
+    return rc;
+  RUN(h, s, "head_l2norm", 0.0, (double)nb * E * 6,
+      launch_l2norm_rows(h->e32, outp, out_dtype, normalize, nb, E, s));
+  return OAKE_OK;
+}
+
 int check_ready(oake_handle* h) {
   const int m = oake_missing_tensors(h);
   if (m != 0) return fail(h, OAKE_ERR_STATE, std::to_string(m) + " weight tensors not loaded");
@@ -499,9 +523,7 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
         return rc;
       if ((rc = main_block_tail(h, s, w, nb))) return rc;
     }
-    RUN(h, s, "head", 2.0 * nb * C * c.embed_dim, 0.0,
-        launch_head(h->dt16, h->x, (long)L * C, h->lnpost_g, h->lnpost_b, h->proj, outp, out_dtype,
-                    normalize, nb, C, c.embed_dim, s));
+    if ((rc = head(h, s, h->x, (long)L * C, outp, out_dtype, normalize, nb))) return rc;
   }
   return OAKE_OK;
 }
@@ -574,9 +596,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       // y in Hooks.transformer_forward, objects.py:249-258)
       if (!last && (rc = main_block_tail(h, s, w, nb))) return rc;
     }
-    RUN(h, s, "head", 2.0 * nb * C * c.embed_dim, 0.0,
-        launch_head(h->dt16, h->y, (long)C, h->lnpost_g, h->lnpost_b, h->proj, outp, out_dtype,
-                    normalize, nb, C, c.embed_dim, s));
+    if ((rc = head(h, s, h->y, (long)C, outp, out_dtype, normalize, nb))) return rc;
   }
   return OAKE_OK;
 }

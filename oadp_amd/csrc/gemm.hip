@@ -596,11 +596,13 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
           deferred = true;
         }
       }
-      if (!deferred) {
-        // last tile of this block (nothing left to hide the stores under), edge tile, or fp32 output
+      if (!deferred && c_tile < my_tiles) {
+        // edge tile or fp32 output with more tiles to come: store now
         tile_epilogue<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, true,
                                       interior);
       }
+      // (the block's LAST tile is stored after the loop: done here, group 0's stores would sit in
+      // front of a barrier and group 1 would start its own epilogue only once they are issued)
       if (tmap.trace != nullptr && (tid & 255) == 0 && blockIdx.x < 64 && c_tile <= 8) {
         OAKE_PIN();
         unsigned long long* tr =
@@ -612,6 +614,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     OAKE_BAR();
   }
   if (!late) OAKE_BAR();
+  {
+    int m0, n0;
+    tile_origin(tmap, xb + xslot + (my_tiles - 1) * per_xcd, BM, BN, m0, n0);
+    tile_epilogue<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, false,
+                                  m0 + BM <= M && n0 + BN <= N);
+  }
 #undef OAKE_STORE_PEND
 #undef OAKE_LOAD_FRAGS
 #undef OAKE_MFMA_BLOCK
@@ -684,6 +692,7 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
 // Configurations.  0: simple 128x128 (4 waves)   1: simple 160x256 (8 waves 2x4)
 //                  2: simple 320x128 (8 waves 4x2)   3: simple 256x256 (8 waves 2x4)
 //                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production]
+//                  5: simple 64x64 (4 waves) for the few-hundred-row problems (head, object stream)
 template <typename T, int EPI>
 hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
   switch (variant) {
@@ -692,12 +701,14 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 2: return launch_simple<T, EPI, 320, 128, 4, 2>(a, s);
     case 3: return launch_simple<T, EPI, 256, 256, 2, 4>(a, s);
     case 4: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
+    case 5: return launch_simple<T, EPI, 64, 64, 2, 2>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 int pick_variant(const GemmArgs& a) {
   if (g_gemm_variant >= 0) return g_gemm_variant;
+  if ((long)a.M * a.N <= 512 * 1024) return 5;  // spread small problems over more CUs
   if (a.M <= 1024 || a.N < 256) return 0;
   return 4;
 }

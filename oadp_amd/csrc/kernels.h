@@ -60,12 +60,10 @@ hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* q
                                    const void* mask, int mask_dtype, void* out, int n, int L,
                                    int heads, hipStream_t s);
 
-// ---- head --------------------------------------------------------------------------------
-// rows[n] = x + n*row_stride (fp32, c wide): ln_post -> @ proj[c, e] (16-bit) -> optional L2
-// normalise -> out [n, e] (fp32 or f16).
-hipError_t launch_head(int dtype16, const float* x, long row_stride, const float* gamma,
-                       const float* beta, const void* proj, void* out, int out_dtype,
-                       int normalize, int n, int c, int e, hipStream_t s);
+// ---- head tail ---------------------------------------------------------------------------
+// rows of [n, e] fp32 -> optional L2 normalise (F.normalize, eps 1e-12) -> out [n, e] (fp32 or f16)
+hipError_t launch_l2norm_rows(const float* in, void* out, int out_dtype, int normalize, int n, int e,
+                              hipStream_t s);
 
 // ---- misc --------------------------------------------------------------------------------
 hipError_t launch_cast_f32_to_16(int dtype16, const float* in, void* out, size_t numel, float scale,

@@ -160,115 +160,38 @@ __global__ __launch_bounds__(256) void im2col_kernel(const TIN* __restrict__ img
   reinterpret_cast<uint4*>(out)[idx] = o;
 }
 
-// ---- head: ln_post -> @proj -> (L2 normalise) -> out ----------------------------------------
-constexpr int kHeadImgs = 4;
-
-template <typename T>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, long row_stride,
-                                                   const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta,
-                                                   const T* __restrict__ proj, void* __restrict__ out,
-                                                   int out_f16, int normalize, int n, int c, int e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ys = reinterpret_cast<float*>(smem);          // [kHeadImgs][c]
-  float* red = ys + kHeadImgs * c;                      // [kHeadImgs][4]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int img0 = blockIdx.x * kHeadImgs;
-
-  {  // LayerNorm of image img0 + wid by wave wid
-    const int img = img0 + wid;
-    const int nv = c >> 2;
-    float4 v[kMaxVec];
-    const bool valid = img < n;
-    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)(valid ? img : 0) * row_stride);
+// ---- head tail: rows of [n, e] fp32 -> optional L2 normalise -> fp16 / fp32 ------------------
+// (ln_post is a layernorm_kernel launch over the CLS rows and `@ proj` a small GEMM: the first
+// version — one block streaming all of proj per 4 crops — took 85 us cold for 0.2 GFLOP.)
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ in,
+                                                          void* __restrict__ out, int out_f16,
+                                                          int normalize, int n, int e) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int nv = e >> 2;  // e % 4 == 0, e <= 1024
+  const float4* ir = reinterpret_cast<const float4*>(in + (size_t)row * e);
+  float4 v[kMaxVec];
+  float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i)
-      if (lane + 64 * i < nv) v[i] = xr[lane + 64 * i];
-    float mean, rstd;
-    ln_stats(v, lane, nv, c, mean, rstd);
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(beta);
-    float4* yw = reinterpret_cast<float4*>(ys + wid * c);
-#pragma unroll
-    for (int i = 0; i < kMaxVec; ++i)
-      if (lane + 64 * i < nv) {
-        const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
-        yw[lane + 64 * i] =
-            make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                        (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
-      }
-  }
-  __syncthreads();
-
-  float ssq[kHeadImgs] = {0.f, 0.f, 0.f, 0.f};
-  // each thread owns output columns j = 2*tid + 512*r (+1)
-  const int nrep = (e + 511) / 512;
-  float acc[2][kHeadImgs][2];  // up to e = 1024
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int i = 0; i < kHeadImgs; ++i) acc[r][i][0] = acc[r][i][1] = 0.f;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    if (r >= nrep) break;
-    const int j = 2 * tid + 512 * r;
-    if (j < e) {
-      for (int k = 0; k < c; ++k) {
-        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(proj + (size_t)k * e + j);
-        typedef T pair_t __attribute__((ext_vector_type(2)));
-        const pair_t w = __builtin_bit_cast(pair_t, w2);
-        const float w0 = to32<T>(w[0]), w1 = to32<T>(w[1]);
-#pragma unroll
-        for (int i = 0; i < kHeadImgs; ++i) {
-          const float yv = ys[i * c + k];
-          acc[r][i][0] += yv * w0;
-          acc[r][i][1] += yv * w1;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < kHeadImgs; ++i)
-        ssq[i] += acc[r][i][0] * acc[r][i][0] + acc[r][i][1] * acc[r][i][1];
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) {
+      v[i] = ir[lane + 64 * i];
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-  }
-  float scale[kHeadImgs];
-  if (normalize) {
+  float scale = 1.0f;
+  if (normalize) scale = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);  // F.normalize eps
 #pragma unroll
-    for (int i = 0; i < kHeadImgs; ++i) {
-      const float s = wave_sum(ssq[i]);
-      if (lane == 0) red[i * 4 + wid] = s;
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) {
+      const float a = v[i].x * scale, b = v[i].y * scale, c = v[i].z * scale, d = v[i].w * scale;
+      if (out_f16)
+        reinterpret_cast<uint2*>(reinterpret_cast<f16_t*>(out) + (size_t)row * e)[lane + 64 * i] =
+            pack4<f16_t>(a, b, c, d);
+      else
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * e)[lane + 64 * i] =
+            make_float4(a, b, c, d);
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kHeadImgs; ++i) {
-      const float tot = (red[i * 4 + 0] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
-      scale[i] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);  // F.normalize eps
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < kHeadImgs; ++i) scale[i] = 1.0f;
-  }
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    if (r >= nrep) break;
-    const int j = 2 * tid + 512 * r;
-    if (j >= e) continue;
-#pragma unroll
-    for (int i = 0; i < kHeadImgs; ++i) {
-      const int img = img0 + i;
-      if (img >= n) continue;
-      const float o0 = acc[r][i][0] * scale[i], o1 = acc[r][i][1] * scale[i];
-      if (out_f16) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        h2 hv;
-        hv[0] = (_Float16)o0;
-        hv[1] = (_Float16)o1;
-        *reinterpret_cast<h2*>(reinterpret_cast<_Float16*>(out) + (size_t)img * e + j) = hv;
-      } else {
-        *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + (size_t)img * e + j) =
-            make_float2(o0, o1);
-      }
-    }
-  }
 }
 
 // ---- casts ----------------------------------------------------------------------------------
@@ -388,23 +311,13 @@ hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, 
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_head(int dtype16, const float* x, long row_stride, const float* gamma,
-                       const float* beta, const void* proj, void* out, int out_dtype, int normalize,
-                       int n, int c, int e, hipStream_t s) {
+hipError_t launch_l2norm_rows(const float* in, void* out, int out_dtype, int normalize, int n, int e,
+                              hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if (c % 4 != 0 || c > kMaxVec * 256 || e % 2 != 0 || e > 1024) return hipErrorInvalidValue;
+  if (e % 4 != 0 || e > kMaxVec * 256) return hipErrorInvalidValue;
   if (out_dtype != DT_F32 && out_dtype != DT_F16) return hipErrorInvalidValue;
-  const int blocks = (n + kHeadImgs - 1) / kHeadImgs;
-  const size_t lds = (size_t)kHeadImgs * c * sizeof(float) + kHeadImgs * 4 * sizeof(float);
-  const int of16 = out_dtype == DT_F16;
-  if (dtype16 == DT_F16)
-    hipLaunchKernelGGL(head_kernel<f16_t>, dim3(blocks), dim3(256), lds, s, x, row_stride, gamma,
-                       beta, reinterpret_cast<const f16_t*>(proj), out, of16, normalize, n, c, e);
-  else if (dtype16 == DT_BF16)
-    hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(blocks), dim3(256), lds, s, x, row_stride, gamma,
-                       beta, reinterpret_cast<const bf16_t*>(proj), out, of16, normalize, n, c, e);
-  else
-    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, in, out,
+                     out_dtype == DT_F16 ? 1 : 0, normalize, n, e);
   return hipGetLastError();
 }
 
