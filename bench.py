@@ -68,6 +68,8 @@ def main() -> None:
     from oadp_amd.weights import synthetic_state_dict
     if 'OAKE_GEMM_VARIANT' in os.environ:  # A/B runs of the GEMM tile configurations
         _lib.load().oake_debug_set_gemm_variant(int(os.environ['OAKE_GEMM_VARIANT']))
+    if 'OAKE_ATTN_VARIANT' in os.environ:
+        _lib.load().oake_debug_set_attention_variant(int(os.environ['OAKE_ATTN_VARIANT']))
     cdt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
     sd = synthetic_state_dict()
     model, _ = clip.load(sd, compute_dtype=cdt, max_batch=args.batch)

@@ -19,7 +19,9 @@
  *   F.normalize(embedding).half()     oadp/oake/globals.py:58-59, blocks.py:130-132,
  *                                     objects.py:331,334   -> `normalize` / `out_dtype` args
  *   preprocess(image.crop(box))       oadp/oake/blocks.py:79-81, objects.py:116-127
- *                                                          -> oake_crop_normalize
+ *                                                          -> oake_crop_normalize (exact-size crops),
+ *                                                             oake_crop_resize_normalize (resampled)
+ *   image.resize((w/1.5, h/1.5))      oadp/oake/blocks.py:72-76 -> oake_resize_u8
  *
  * Conventions: plain C, int status (0 = OAKE_OK), no exception crosses the ABI.  All data
  * pointers named d_* are DEVICE pointers owned by the caller (e.g. a torch tensor's
@@ -157,6 +159,24 @@ OAKE_API int oake_crop_normalize(oake_handle* h, const uint8_t* d_image_hwc, int
                         void* d_out, int out_dtype, void* stream);
 
 /*
+ * `preprocess(image.crop(box))` of the reference's DataLoader workers, on the device and bit-exact
+ * with Pillow/torchvision (oadp/oake/objects.py:116-127, globals.py:26-33): for each of k boxes
+ * (x1,y1,x2,y2 HOST floats) PIL Image.crop (round-half-even coordinates, zero fill outside the
+ * image), Resize(out_size, BICUBIC) — Pillow's antialiased fixed-point two-pass resampler — CenterCrop,
+ * ToTensor and Normalize(mean, std).  squash != 0 resizes straight to out_size x out_size instead
+ * (our reading of clip.load_default(True)).  d_out is [k,3,out,out] NCHW of out_dtype (F32|F16).
+ */
+OAKE_API int oake_crop_resize_normalize(oake_handle* h, const uint8_t* d_image_hwc, int height, int width,
+                               const float* h_boxes_xyxy, int k, int out_size, int squash,
+                               const float* h_mean3, const float* h_std3,
+                               void* d_out, int out_dtype, void* stream);
+
+/* PIL Image.resize((dw, dh)) (default BICUBIC) of a uint8 HWC RGB device image — the pyramid step of
+ * oadp/oake/blocks.py:72-76 — bit-exact with Pillow. */
+OAKE_API int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw,
+                   uint8_t* d_dst_hwc, int dh, int dw, void* stream);
+
+/*
  * Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
  * enable=1 brackets every kernel launch with events; oake_profile_read synchronises and
  * returns, for up to `cap` kernel slots, name / total milliseconds / launch count / flops.
@@ -193,8 +213,9 @@ OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, 
                          int dtype16, void* stream);
 /* Raw ds_read_b64_tr_b16 semantics probe: in = 256 uint16, out = 64 lanes x 4 uint16. */
 OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
-/* Attention V-fragment path: 0 = 16-bit LDS gathers, 1 = ds_read_b64_tr_b16 transpose reads. */
-OAKE_API int oake_debug_set_attention_variant(int use_tr);
+/* Attention variant bits: 1 = ds_read_b64_tr_b16 V fragments (else 16-bit LDS gathers),
+ * 2 = 32 queries per wave (else 64).  Default 3. */
+OAKE_API int oake_debug_set_attention_variant(int variant);
 /* GEMM configuration: -1 = automatic per shape, 0..4 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
 /* Debug: device buffer of 64*2*8*4 uint64 receiving per-tile cycle stamps of the production GEMM

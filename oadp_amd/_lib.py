@@ -39,6 +39,9 @@ SIGNATURES = {
     'oake_encode_objects': (_I, [_VP, _VP, _I, _VP, _I, _I, _VP, _I, _I, _VP]),
     'oake_crop_normalize': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, C.POINTER(C.c_float),
                                  C.POINTER(C.c_float), _VP, _I, _VP]),
+    'oake_crop_resize_normalize': (_I, [_VP, _VP, _I, _I, C.POINTER(C.c_float), _I, _I, _I,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float), _VP, _I, _VP]),
+    'oake_resize_u8': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     'oake_profile_enable': (_I, [_VP, _I]),
     'oake_profile_read': (_I, [_VP, C.POINTER(ProfileEntry), _I, C.POINTER(_I)]),
     'oake_profile_reset': (_I, [_VP]),

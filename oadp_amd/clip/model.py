@@ -200,6 +200,68 @@ class VisionTransformer:
                 _lib.check(lib, h, rc, 'oake_encode_objects')
         return out if out.dtype == out_dtype else out.to(out_dtype)
 
+    # -- device-side preprocessing (csrc/resample.hip, rowops.hip) -------------------------------
+    def _image_args(self, image_u8: torch.Tensor):
+        if not image_u8.is_cuda or image_u8.dtype != torch.uint8 or image_u8.dim() != 3 or image_u8.shape[2] != 3:
+            raise ValueError('expected a uint8 HWC RGB tensor on the GPU')
+        dev = image_u8.device.index if image_u8.device.index is not None else torch.cuda.current_device()
+        return image_u8.contiguous(), dev
+
+    def crop_resize_normalize(self, image_u8: torch.Tensor, boxes, *, squash: bool = False,
+                              out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """``torch.stack([preprocess(image.crop(box)) for box in boxes])`` on the device, bit-exact
+        with Pillow + torchvision (Image.crop, Resize(n, BICUBIC), CenterCrop, ToTensor, Normalize).
+        ``boxes``: [k,4] float (x1,y1,x2,y2), any device."""
+        from .preprocess import CLIP_MEAN, CLIP_STD
+        image_u8, dev = self._image_args(image_u8)
+        boxes = torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 4).cpu().contiguous()
+        k, n = boxes.shape[0], self.input_resolution
+        out = torch.empty((k, 3, n, n), dtype=out_dtype, device=image_u8.device)
+        if k == 0:
+            return out
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            mean, std = (C.c_float * 3)(*CLIP_MEAN), (C.c_float * 3)(*CLIP_STD)
+            rc = self._lib.oake_crop_resize_normalize(
+                h, image_u8.data_ptr(), image_u8.shape[0], image_u8.shape[1],
+                C.cast(boxes.data_ptr(), C.POINTER(C.c_float)), k, n, int(squash), mean, std,
+                out.data_ptr(), _TORCH2OAKE[out_dtype], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_crop_resize_normalize')
+        return out
+
+    def resize_u8(self, image_u8: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
+        """``PIL.Image.resize(size)`` (bicubic) of a uint8 HWC device image; ``size`` = (w, h)."""
+        image_u8, dev = self._image_args(image_u8)
+        w, h_ = int(size[0]), int(size[1])
+        out = torch.empty((h_, w, 3), dtype=torch.uint8, device=image_u8.device)
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            rc = self._lib.oake_resize_u8(h, image_u8.data_ptr(), image_u8.shape[0], image_u8.shape[1],
+                                          out.data_ptr(), h_, w,
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_resize_u8')
+        return out
+
+    def crop_normalize(self, image_u8: torch.Tensor, boxes_xyxy, *,
+                       out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """Exact-size (n x n) integer crops + ToTensor + Normalize (blocks of one pyramid level)."""
+        from .preprocess import CLIP_MEAN, CLIP_STD
+        image_u8, dev = self._image_args(image_u8)
+        boxes = torch.as_tensor(boxes_xyxy, dtype=torch.int32).reshape(-1, 4).to(image_u8.device).contiguous()
+        k, n = boxes.shape[0], self.input_resolution
+        out = torch.empty((k, 3, n, n), dtype=out_dtype, device=image_u8.device)
+        if k == 0:
+            return out
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            mean, std = (C.c_float * 3)(*CLIP_MEAN), (C.c_float * 3)(*CLIP_STD)
+            rc = self._lib.oake_crop_normalize(h, image_u8.data_ptr(), image_u8.shape[0], image_u8.shape[1],
+                                               boxes.data_ptr(), k, n, mean, std, out.data_ptr(),
+                                               _TORCH2OAKE[out_dtype],
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_crop_normalize')
+        return out
+
     # -- profiler (bench.py) ---------------------------------------------------------------
     def profile(self, enable: bool) -> None:
         if self._handle is None:

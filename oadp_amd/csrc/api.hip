@@ -12,6 +12,7 @@
 //                  last layer's main stream (never read) is not executed.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -23,6 +24,7 @@
 
 namespace oake {
 extern int g_attention_use_tr;
+extern int g_attention_q32;
 extern int g_gemm_variant;
 extern unsigned long long* g_gemm_trace;
 }
@@ -78,6 +80,13 @@ struct oake_handle {
   float* y = nullptr;
   float* e32 = nullptr;       // [B, embed] fp32 head projection
   void *yn = nullptr, *qkv_y = nullptr, *att_y = nullptr, *h_y = nullptr;
+
+  // resample scratch (grown on demand)
+  ResampleJob* rs_jobs = nullptr;
+  int32_t* rs_coef = nullptr;
+  int32_t* rs_bounds = nullptr;
+  uint8_t* rs_temp = nullptr;
+  size_t rs_jobs_cap = 0, rs_coef_cap = 0, rs_bounds_cap = 0, rs_temp_cap = 0;
 
   // profiler
   bool prof = false;
@@ -228,7 +237,7 @@ void oake_destroy(oake_handle* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
-                  h->yn, h->qkv_y, h->att_y, h->h_y};
+                  h->yn, h->qkv_y, h->att_y, h->h_y, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& l : h->layers) {
@@ -488,6 +497,64 @@ size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : (dt == DT_U8 ? 1 : 2); }
 
 }  // namespace
 
+namespace {
+
+template <typename P>
+int grow(oake_handle* h, hipStream_t s, P** p, size_t* cap, size_t need_bytes) {
+  if (need_bytes <= *cap) return OAKE_OK;
+  HIP_TRY(h, hipStreamSynchronize(s));
+  if (*p) HIP_TRY(h, hipFree(*p));
+  *p = nullptr;
+  const size_t bytes = need_bytes + need_bytes / 4 + 4096;
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(p), bytes));
+  *cap = bytes;
+  return OAKE_OK;
+}
+
+int ksize_for(int in_size, int out_size) {
+  if (in_size == out_size) return 1;
+  double filterscale = (double)((float)in_size) / out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  return (int)std::ceil(2.0 * filterscale) * 2 + 1;  // Pillow: (int)ceil(support) * 2 + 1
+}
+
+// jobs -> device, scratch sizing, launch.  `jobs` offsets are filled here.
+int run_resample(oake_handle* h, hipStream_t s, const uint8_t* d_img, int height, int width,
+                 std::vector<ResampleJob>& jobs, int out_size, const float* mean3, const float* std3,
+                 void* d_out, int out_dtype) {
+  long coef = 0, bnd = 0, temp = 0;
+  int max_out = 1;
+  long max_ch_rw = 1;
+  for (auto& j : jobs) {
+    j.kh = ksize_for(j.cw, j.rw);
+    j.kv = ksize_for(j.ch, j.rh);
+    j.coefh_off = coef; coef += (long)j.rw * j.kh;
+    j.coefv_off = coef; coef += (long)j.rh * j.kv;
+    j.boundh_off = bnd; bnd += 2L * j.rw;
+    j.boundv_off = bnd; bnd += 2L * j.rh;
+    j.temp_off = temp; temp += (long)j.ch * j.rw * 3;
+    max_out = std::max(max_out, std::max(j.rw, j.rh));
+    max_ch_rw = std::max(max_ch_rw, (long)j.ch * j.rw);
+  }
+  if (max_ch_rw > 0x7fffffffL) return fail(h, OAKE_ERR_INVALID, "crop too large");
+  int rc;
+  if ((rc = grow(h, s, &h->rs_jobs, &h->rs_jobs_cap, jobs.size() * sizeof(ResampleJob)))) return rc;
+  if ((rc = grow(h, s, &h->rs_coef, &h->rs_coef_cap, (size_t)coef * 4))) return rc;
+  if ((rc = grow(h, s, &h->rs_bounds, &h->rs_bounds_cap, (size_t)bnd * 4))) return rc;
+  if ((rc = grow(h, s, &h->rs_temp, &h->rs_temp_cap, (size_t)temp))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->rs_jobs, jobs.data(), jobs.size() * sizeof(ResampleJob),
+                            hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipStreamSynchronize(s));  // `jobs` is a host temporary
+  const double bytes = (double)temp * 2 + (double)jobs.size() * out_size * out_size * 3 * 4;
+  RUN(h, s, "resample", 0.0, bytes,
+      launch_resample(d_img, height, width, h->rs_jobs, (int)jobs.size(), max_out, (int)max_ch_rw,
+                      h->rs_coef, h->rs_bounds, h->rs_temp, out_size, mean3, std3, d_out, out_dtype,
+                      s));
+  return OAKE_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n, void* d_out,
@@ -621,6 +688,64 @@ int oake_crop_normalize(oake_handle* h, const uint8_t* d_image_hwc, int height, 
   return OAKE_OK;
 }
 
+int oake_crop_resize_normalize(oake_handle* h, const uint8_t* d_image_hwc, int height, int width,
+                               const float* h_boxes_xyxy, int k, int out_size, int squash,
+                               const float* h_mean3, const float* h_std3, void* d_out, int out_dtype,
+                               void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (k < 0 || height <= 0 || width <= 0 || out_size <= 0)
+    return fail(h, OAKE_ERR_INVALID, "bad crop geometry");
+  if (k == 0) return OAKE_OK;
+  if (!d_image_hwc || !h_boxes_xyxy || !d_out || !h_mean3 || !h_std3)
+    return fail(h, OAKE_ERR_INVALID, "null pointer");
+  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<ResampleJob> jobs(k);
+  for (int i = 0; i < k; ++i) {
+    ResampleJob& j = jobs[i];
+    // PIL Image.crop: every coordinate through Python round() (ties to even), zero fill outside
+    const int x0 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 0]);
+    const int y0 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 1]);
+    const int x1 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 2]);
+    const int y1 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 3]);
+    j.sx0 = x0; j.sy0 = y0; j.cw = x1 - x0; j.ch = y1 - y0;
+    if (j.cw <= 0 || j.ch <= 0) return fail(h, OAKE_ERR_INVALID, "empty crop box");
+    if (squash) {
+      j.rw = j.rh = out_size;
+      j.cx = j.cy = 0;
+    } else {
+      // torchvision Resize(int) on a PIL image, then CenterCrop
+      if ((j.cw <= j.ch && j.cw == out_size) || (j.ch <= j.cw && j.ch == out_size)) {
+        j.rw = j.cw; j.rh = j.ch;
+      } else if (j.cw < j.ch) {
+        j.rw = out_size; j.rh = (int)((double)((long)out_size * j.ch) / (double)j.cw);
+      } else {
+        j.rh = out_size; j.rw = (int)((double)((long)out_size * j.cw) / (double)j.ch);
+      }
+      j.cy = (int)std::nearbyint((j.rh - out_size) / 2.0);
+      j.cx = (int)std::nearbyint((j.rw - out_size) / 2.0);
+    }
+  }
+  return run_resample(h, s, d_image_hwc, height, width, jobs, out_size, h_mean3, h_std3, d_out,
+                      out_dtype);
+}
+
+int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw, uint8_t* d_dst_hwc,
+                   int dh, int dw, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || !d_src_hwc || !d_dst_hwc)
+    return fail(h, OAKE_ERR_INVALID, "bad resize arguments");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<ResampleJob> jobs(1);
+  ResampleJob& j = jobs[0];
+  j.sx0 = j.sy0 = 0; j.cw = sw; j.ch = sh; j.rw = dw; j.rh = dh; j.cx = j.cy = 0;
+  const float z[3] = {0.f, 0.f, 0.f}, o[3] = {1.f, 1.f, 1.f};
+  return run_resample(h, s, d_src_hwc, sh, sw, jobs, 0, z, o, d_dst_hwc, OAKE_U8);
+}
+
 int oake_profile_enable(oake_handle* h, int enable) {
   if (!h) return OAKE_ERR_INVALID;
   if (!enable) prof_collect(h);
@@ -696,8 +821,10 @@ int oake_debug_set_gemm_trace(void* d_trace) {
   return OAKE_OK;
 }
 
-int oake_debug_set_attention_variant(int use_tr) {
-  oake::g_attention_use_tr = use_tr ? 1 : 0;
+int oake_debug_set_attention_variant(int variant) {
+  // bit 0: ds_read_b64_tr_b16 V fragments (else 16-bit gathers); bit 1: 32 queries per wave (else 64)
+  oake::g_attention_use_tr = (variant & 1) ? 1 : 0;
+  oake::g_attention_q32 = (variant & 2) ? 1 : 0;
   return OAKE_OK;
 }
 

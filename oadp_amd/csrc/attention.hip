@@ -27,7 +27,7 @@ namespace {
 constexpr int kVStride = 72;                       // halves per V row in LDS (64 + 8 pad = 144 B)
 constexpr int kVBytesPerWave = 64 * kVStride * 2;  // 9216
 
-template <typename T, bool USE_TR>
+template <typename T, bool USE_TR, int MT>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int L, int H, int QB,
                                                         int total_waves) {
@@ -46,13 +46,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   const T* base = qkv + (size_t)img * L * ld + h * kHeadDim;
   const int fr = lane & 15;
   const int g = lane >> 4;
-  const int q0 = qb * 64;
+  const int q0 = qb * (16 * MT);
   T* vs = reinterpret_cast<T*>(smem + wid * kVBytesPerWave);
 
   // Q fragments (B operand): Q[q0 + 16 mt + fr][32 kk + 8 g .. +8)
-  vec8 qf[4][2];
+  vec8 qf[MT][2];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     int r = q0 + mt * 16 + fr;
     r = r < L ? r : L - 1;
 #pragma unroll
@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
       qf[mt][kk] = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + kk * 32 + g * 8);
   }
 
-  float m_run[4], l_run[4];
-  f32x4 oacc[4][4];  // [dt][mt] : O^T tile, rows d = 16 dt + 4 g + r, col query = 16 mt + fr
+  float m_run[MT], l_run[MT];
+  f32x4 oacc[4][MT];  // [dt][mt] : O^T tile, rows d = 16 dt + 4 g + r, col query = 16 mt + fr
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     m_run[mt] = -1e30f;
     l_run[mt] = 0.f;
 #pragma unroll
@@ -74,42 +74,62 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   for (int kc = 0; kc < nchunks; ++kc) {
     const int k0 = kc * 64;
 
-    // ---- stage V[k0 .. k0+64) into LDS: lane -> (row = lane/8 + 8 i, 16-B chunk = lane%8) ----
+    // ---- issue ALL global loads of this chunk up front (V rows for the LDS stage, K fragments), so
+    //      the wave pays one memory latency, not two ----
+    uint4 vreg[8];
     {
       const int vr = lane >> 3, vc = lane & 7;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         int r = k0 + vr + 8 * i;
         r = r < L ? r : L - 1;  // finite filler for padded keys (their P is exactly 0)
-        const uint4 v =
-            *reinterpret_cast<const uint4*>(base + (size_t)r * ld + 2 * C + vc * 8);
-        *reinterpret_cast<uint4*>(vs + (vr + 8 * i) * kVStride + vc * 8) = v;
+        vreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + 2 * C + vc * 8);
       }
+    }
+    vec8 kfr[MT == 2 ? 4 : 1][2];
+    if (MT == 2) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        int r = k0 + kt * 16 + fr;
+        r = r < L ? r : L - 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          kfr[kt][kk] = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + C + kk * 32 + g * 8);
+      }
+    }
+    {  // V -> LDS: lane -> (row = lane/8 + 8 i, 16-B chunk = lane%8)
+      const int vr = lane >> 3, vc = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<uint4*>(vs + (vr + 8 * i) * kVStride + vc * 8) = vreg[i];
     }
 
     // ---- S^T[key][query] tiles ----
-    f32x4 sacc[4][4];  // [kt][mt]
+    f32x4 sacc[4][MT];  // [kt][mt]
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       int r = k0 + kt * 16 + fr;
       r = r < L ? r : L - 1;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const vec8 kf =
-            *reinterpret_cast<const vec8*>(base + (size_t)r * ld + C + kk * 32 + g * 8);
+        vec8 kf;
+        if (MT == 2)
+          kf = kfr[kt][kk];
+        else
+          kf = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + C + kk * 32 + g * 8);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
+        for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
       }
     }
 
     // ---- online softmax over this chunk's keys; lane owns query 16 mt + fr ----
-    vec8 pf[4][2];  // [mt][ks] : B operand of the PV MFMA
+    vec8 pf[MT][2];  // [mt][ks] : B operand of the PV MFMA
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       float mx = -1e30f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
             vf[j] = vs[(32 * ks + 16 * (j >> 2) + 4 * g + (j & 3)) * kVStride + dt * 16 + fr];
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ks], oacc[dt][mt]);
+        for (int mt = 0; mt < MT; ++mt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ks], oacc[dt][mt]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   // ---- normalise and store: lane holds O[query = 16 mt + fr][d = 16 dt + 4 g + 0..3] ----
   T* obase = out + (size_t)img * L * C + h * kHeadDim;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int q = q0 + mt * 16 + fr;
     if (q >= L) continue;
     const float inv = 1.0f / l_run[mt];
@@ -290,32 +310,35 @@ __global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* 
 }  // namespace
 
 // 0 = 16-bit LDS gathers for the V fragments, 1 = ds_read_b64_tr_b16 (set by api.hip)
-int g_attention_use_tr = 0;
+int g_attention_use_tr = 1;
+
+// 0 = 64 queries per wave, 1 = 32 queries per wave (half the registers, twice the waves)
+int g_attention_q32 = 1;
+
+template <typename T, int MT>
+static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, hipStream_t s) {
+  const int QB = (L + 16 * MT - 1) / (16 * MT);
+  const int tw = n * heads * QB;
+  const dim3 g((tw + 3) / 4), b(256);
+  const T* in = reinterpret_cast<const T*>(qkv);
+  T* o = reinterpret_cast<T*>(out);
+  if (g_attention_use_tr)
+    hipLaunchKernelGGL((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw);
+  else
+    hipLaunchKernelGGL((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw);
+}
 
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
                             hipStream_t s) {
   if (n <= 0) return hipSuccess;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
-  const int QB = (L + 63) / 64;
-  const long total = (long)n * heads * QB;
-  if (total > 0x7fffffffL) return hipErrorInvalidValue;
-  const int blocks = (int)((total + 3) / 4);
-  const dim3 g(blocks), b(256);
-  const int tw = (int)total;
+  if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
   if (dtype16 == DT_F16) {
-    const f16_t* in = reinterpret_cast<const f16_t*>(qkv);
-    f16_t* o = reinterpret_cast<f16_t*>(out);
-    if (g_attention_use_tr)
-      hipLaunchKernelGGL((attention_kernel<f16_t, true>), g, b, 0, s, in, o, L, heads, QB, tw);
-    else
-      hipLaunchKernelGGL((attention_kernel<f16_t, false>), g, b, 0, s, in, o, L, heads, QB, tw);
+    if (g_attention_q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, s);
+    else attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, s);
   } else if (dtype16 == DT_BF16) {
-    const bf16_t* in = reinterpret_cast<const bf16_t*>(qkv);
-    bf16_t* o = reinterpret_cast<bf16_t*>(out);
-    if (g_attention_use_tr)
-      hipLaunchKernelGGL((attention_kernel<bf16_t, true>), g, b, 0, s, in, o, L, heads, QB, tw);
-    else
-      hipLaunchKernelGGL((attention_kernel<bf16_t, false>), g, b, 0, s, in, o, L, heads, QB, tw);
+    if (g_attention_q32) attn_launch_t<bf16_t, 2>(qkv, out, n, L, heads, s);
+    else attn_launch_t<bf16_t, 4>(qkv, out, n, L, heads, s);
   } else {
     return hipErrorInvalidValue;
   }

@@ -75,6 +75,23 @@ hipError_t launch_crop_normalize(const uint8_t* img, int height, int width, cons
                                  int k, int out_size, const float* mean3, const float* inv_std3,
                                  void* out, int out_dtype, hipStream_t s);
 
+// ---- Pillow-exact crop + bicubic resize (resample.hip) --------------------------------------
+struct ResampleJob {
+  int sx0, sy0;        // crop origin in the source image (may be negative: PIL zero-fills)
+  int cw, ch;          // crop size
+  int rw, rh;          // size after Resize
+  int cx, cy;          // CenterCrop offset into the resized image
+  int kh, kv;          // coefficient taps per output index (horizontal / vertical)
+  long coefh_off, coefv_off;    // offsets into the int32 coefficient table
+  long boundh_off, boundv_off;  // offsets into the int32 bounds table
+  long temp_off;       // byte offset of this job's horizontal-pass image
+};
+// out_dtype DT_F32 / DT_F16: [njobs,3,out,out] normalised crops; DT_U8: one HWC uint8 image (rh x rw).
+hipError_t launch_resample(const uint8_t* img, int height, int width, const ResampleJob* d_jobs,
+                           int njobs, int max_out, int max_ch_rw, int32_t* d_coef, int32_t* d_bounds,
+                           uint8_t* d_temp, int out_size, const float* mean3, const float* std3,
+                           void* out, int out_dtype, hipStream_t s);
+
 hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s);
 
 }  // namespace oake

@@ -1,0 +1,237 @@
+// resample.hip — Pillow-exact antialiased bicubic crop + resize + ToTensor + Normalize on the GPU.
+//
+// The reference's DataLoader workers run `preprocess(image.crop(box))` with PIL on the CPU
+// (oadp/oake/objects.py:116-127, blocks.py:54-81, globals.py:26-33): Image.crop (zero fill outside
+// the image), torchvision Resize(224, BICUBIC) = PIL.Image.resize, CenterCrop, ToTensor, Normalize.
+// This file restates Pillow's 8-bit resampler (src/libImaging/Resample.c: precompute_coeffs,
+// normalize_coeffs_8bpc, ImagingResampleHorizontal/Vertical_8bpc) so that the device result is
+// BIT-EXACT with PIL's uint8 pixels (tests/test_resample_gpu.py compares against PIL itself):
+//   * coefficients in double precision with Pillow's exact operation order (no FMA contraction),
+//     filter support scaled by the downscale factor (antialiasing), normalised, then converted to
+//     22-bit fixed point with Pillow's rounding;
+//   * two passes, horizontal then vertical, with the intermediate image rounded and clipped to
+//     uint8 exactly like Pillow's temporary image;
+//   * the final uint8 pixel goes through ToTensor (/255) and Normalize ((x - mean) / std) in fp32.
+// One uint8 HWC source image is uploaded once; all crops of that image are produced by three kernel
+// launches (coefficients, horizontal, vertical+normalise).
+#include "common.h"
+#include "kernels.h"
+
+namespace oake {
+
+namespace {
+
+#pragma clang fp contract(off)
+
+constexpr int kPrecisionBits = 32 - 8 - 2;  // Pillow: PRECISION_BITS
+
+__device__ __forceinline__ double bicubic_filter(double x) {
+  // Pillow bicubic_filter, a = -0.5
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+// One thread = one output index of one axis of one job: Pillow precompute_coeffs +
+// normalize_coeffs_8bpc for that index.  coef layout: [out index][ksize] int32, bounds [out index][2].
+__global__ void resample_coeffs_kernel(const ResampleJob* __restrict__ jobs, int njobs,
+                                       int32_t* __restrict__ coef, int32_t* __restrict__ bounds) {
+  const int job = blockIdx.y;
+  const int axis = blockIdx.z;  // 0 = horizontal, 1 = vertical
+  const ResampleJob jb = jobs[job];
+  const int in_size = axis == 0 ? jb.cw : jb.ch;
+  const int out_size = axis == 0 ? jb.rw : jb.rh;
+  const int ksize = axis == 0 ? jb.kh : jb.kv;
+  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xx >= out_size) return;
+  int32_t* k_out = coef + (axis == 0 ? jb.coefh_off : jb.coefv_off) + (long)xx * ksize;
+  int32_t* b_out = bounds + (axis == 0 ? jb.boundh_off : jb.boundv_off) + 2L * xx;
+
+  double filterscale, scale;
+  filterscale = scale = (double)((float)in_size - 0.0f) / out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 2.0 * filterscale;  // bicubic support 2.0
+  const double center = 0.0 + (xx + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) ww += bicubic_filter((x + xmin - center + 0.5) * ss);
+  for (int x = 0; x < ksize; ++x) {
+    double w = 0.0;
+    if (x < xmax) {
+      w = bicubic_filter((x + xmin - center + 0.5) * ss);
+      if (ww != 0.0) w /= ww;
+    }
+    int32_t kq;
+    if (w < 0)
+      kq = (int)(-0.5 + w * (1 << kPrecisionBits));
+    else
+      kq = (int)(0.5 + w * (1 << kPrecisionBits));
+    k_out[x] = kq;
+  }
+  b_out[0] = xmin;
+  b_out[1] = xmax;
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+  v >>= kPrecisionBits;
+  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// Horizontal pass: temp[job][y][x][c] for y in [0,ch), x in [0,rw).  Source = crop window of the
+// HWC image with PIL's zero fill outside.  (Identity when cw == rw: Pillow skips the pass.)
+__global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ img, int height,
+                                                         int width,
+                                                         const ResampleJob* __restrict__ jobs,
+                                                         const int32_t* __restrict__ coef,
+                                                         const int32_t* __restrict__ bounds,
+                                                         uint8_t* __restrict__ temp) {
+  const ResampleJob jb = jobs[blockIdx.y];
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)jb.ch * jb.rw) return;
+  const int y = idx / jb.rw, x = idx - (long)y * jb.rw;
+  const int sy = jb.sy0 + y;
+  const bool row_ok = sy >= 0 && sy < height;
+  uint8_t* o = temp + jb.temp_off + idx * 3;
+  if (jb.cw == jb.rw) {
+    const int sx = jb.sx0 + x;
+    const bool ok = row_ok && sx >= 0 && sx < width;
+    const uint8_t* p = img + ((long)sy * width + sx) * 3;
+    o[0] = ok ? p[0] : 0;
+    o[1] = ok ? p[1] : 0;
+    o[2] = ok ? p[2] : 0;
+    return;
+  }
+  const int32_t* k = coef + jb.coefh_off + (long)x * jb.kh;
+  const int xmin = bounds[jb.boundh_off + 2L * x], cnt = bounds[jb.boundh_off + 2L * x + 1];
+  int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
+  if (row_ok) {
+    const uint8_t* rowp = img + (long)sy * width * 3;
+    for (int t = 0; t < cnt; ++t) {
+      const int sx = jb.sx0 + xmin + t;
+      if (sx >= 0 && sx < width) {
+        const uint8_t* p = rowp + (long)sx * 3;
+        const int kv = k[t];
+        s0 += p[0] * kv;
+        s1 += p[1] * kv;
+        s2 += p[2] * kv;
+      }
+    }
+  }
+  o[0] = clip8(s0);
+  o[1] = clip8(s1);
+  o[2] = clip8(s2);
+}
+
+// Vertical pass + CenterCrop + ToTensor + Normalize: out[job][c][oy][ox].
+template <typename TOUT>
+__global__ __launch_bounds__(256) void resample_v_kernel(const ResampleJob* __restrict__ jobs,
+                                                         const int32_t* __restrict__ coef,
+                                                         const int32_t* __restrict__ bounds,
+                                                         const uint8_t* __restrict__ temp, int out_size,
+                                                         float m0, float m1, float m2, float d0,
+                                                         float d1, float d2, TOUT* __restrict__ out) {
+  const ResampleJob jb = jobs[blockIdx.y];
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= out_size * out_size) return;
+  const int oy = p / out_size, ox = p - oy * out_size;
+  const int ry = oy + jb.cy, rx = ox + jb.cx;  // position in the resized image
+  float r = 0.f, g = 0.f, b = 0.f;
+  if (ry >= 0 && ry < jb.rh && rx >= 0 && rx < jb.rw) {
+    const uint8_t* tcol = temp + jb.temp_off + (long)rx * 3;
+    int v0, v1, v2;
+    if (jb.ch == jb.rh) {
+      const uint8_t* q = tcol + (long)ry * jb.rw * 3;
+      v0 = q[0]; v1 = q[1]; v2 = q[2];
+    } else {
+      const int32_t* k = coef + jb.coefv_off + (long)ry * jb.kv;
+      const int ymin = bounds[jb.boundv_off + 2L * ry], cnt = bounds[jb.boundv_off + 2L * ry + 1];
+      int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
+      for (int t = 0; t < cnt; ++t) {
+        const uint8_t* q = tcol + (long)(ymin + t) * jb.rw * 3;
+        const int kv = k[t];
+        s0 += q[0] * kv;
+        s1 += q[1] * kv;
+        s2 += q[2] * kv;
+      }
+      v0 = clip8(s0); v1 = clip8(s1); v2 = clip8(s2);
+    }
+    r = (float)v0; g = (float)v1; b = (float)v2;
+  }
+  const size_t plane = (size_t)out_size * out_size;
+  TOUT* o = out + (size_t)blockIdx.y * 3 * plane + p;
+  o[0] = (TOUT)((r / 255.0f - m0) / d0);
+  o[plane] = (TOUT)((g / 255.0f - m1) / d1);
+  o[2 * plane] = (TOUT)((b / 255.0f - m2) / d2);
+}
+
+// Vertical pass to a uint8 HWC image (whole-image resize for the blocks pyramid).
+__global__ __launch_bounds__(256) void resample_v_u8_kernel(const ResampleJob* __restrict__ jobs,
+                                                            const int32_t* __restrict__ coef,
+                                                            const int32_t* __restrict__ bounds,
+                                                            const uint8_t* __restrict__ temp,
+                                                            uint8_t* __restrict__ out) {
+  const ResampleJob jb = jobs[0];
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)jb.rh * jb.rw) return;
+  const int ry = p / jb.rw, rx = p - (long)ry * jb.rw;
+  const uint8_t* tcol = temp + jb.temp_off + (long)rx * 3;
+  uint8_t* o = out + p * 3;
+  if (jb.ch == jb.rh) {
+    const uint8_t* q = tcol + (long)ry * jb.rw * 3;
+    o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+    return;
+  }
+  const int32_t* k = coef + jb.coefv_off + (long)ry * jb.kv;
+  const int ymin = bounds[jb.boundv_off + 2L * ry], cnt = bounds[jb.boundv_off + 2L * ry + 1];
+  int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
+  for (int t = 0; t < cnt; ++t) {
+    const uint8_t* q = tcol + (long)(ymin + t) * jb.rw * 3;
+    const int kv = k[t];
+    s0 += q[0] * kv;
+    s1 += q[1] * kv;
+    s2 += q[2] * kv;
+  }
+  o[0] = clip8(s0);
+  o[1] = clip8(s1);
+  o[2] = clip8(s2);
+}
+
+}  // namespace
+
+hipError_t launch_resample(const uint8_t* img, int height, int width, const ResampleJob* d_jobs,
+                           int njobs, int max_out, int max_ch_rw, int32_t* d_coef, int32_t* d_bounds,
+                           uint8_t* d_temp, int out_size, const float* mean3, const float* std3,
+                           void* out, int out_dtype, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(resample_coeffs_kernel, dim3((max_out + 63) / 64, njobs, 2), dim3(64), 0, s,
+                     d_jobs, njobs, d_coef, d_bounds);
+  hipLaunchKernelGGL(resample_h_kernel, dim3((max_ch_rw + 255) / 256, njobs), dim3(256), 0, s, img,
+                     height, width, d_jobs, d_coef, d_bounds, d_temp);
+  if (out_dtype == DT_U8) {
+    // whole-image resize (njobs == 1): max_out * max_out bounds rh * rw
+    hipLaunchKernelGGL(resample_v_u8_kernel, dim3(((long)max_out * max_out + 255) / 256), dim3(256), 0,
+                       s, d_jobs, d_coef, d_bounds, d_temp, reinterpret_cast<uint8_t*>(out));
+    return hipGetLastError();
+  }
+  const dim3 g((out_size * out_size + 255) / 256, njobs), b(256);
+  if (out_dtype == DT_F32)
+    hipLaunchKernelGGL(resample_v_kernel<float>, g, b, 0, s, d_jobs, d_coef, d_bounds, d_temp,
+                       out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+                       reinterpret_cast<float*>(out));
+  else if (out_dtype == DT_F16)
+    hipLaunchKernelGGL(resample_v_kernel<f16_t>, g, b, 0, s, d_jobs, d_coef, d_bounds, d_temp,
+                       out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+                       reinterpret_cast<f16_t*>(out));
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace oake

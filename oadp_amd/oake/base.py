@@ -51,14 +51,18 @@ class CocoImages:
 
 
 class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
+    _device_preprocess = False
 
     def __init__(self, root: str, annFile: str, *, auto_fix: bool = False, output_dir: str,
-                 transform=None, **kwargs) -> None:
+                 transform=None, device_preprocess: bool = False, **kwargs) -> None:
         self.coco = CocoImages(root, annFile)
         self.root = root
         self.ids = self.coco.ids
         self.transform = transform
         self._auto_fix = auto_fix
+        # True: workers only decode; crop / antialiased-bicubic resize / normalise run on the GPU
+        # (csrc/resample.hip, bit-exact with the PIL path) — needs a HIP device in the main process
+        self._device_preprocess = device_preprocess
         self._output_dir = pathlib.Path(output_dir)
         self._output_dir.mkdir(parents=True, exist_ok=True)
 
@@ -94,6 +98,12 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
     @abstractmethod
     def _preprocess(self, id_: int, output: pathlib.Path, image: PIL.Image.Image) -> T:
         pass
+
+
+def image_to_u8(image: PIL.Image.Image) -> torch.Tensor:
+    """RGB PIL image -> uint8 HWC tensor (what the device preprocessing kernels consume)."""
+    import numpy as np
+    return torch.from_numpy(np.asarray(image.convert('RGB'), dtype=np.uint8).copy())
 
 
 def parse_args(argv: list[str] | None = None) -> argparse.Namespace:

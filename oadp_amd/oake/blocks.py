@@ -11,7 +11,7 @@ import torch
 
 from .. import clip
 from ..config import Config
-from .base import BaseDataset, BaseValidator
+from .base import BaseDataset, BaseValidator, image_to_u8
 
 
 class Batch(NamedTuple):
@@ -58,6 +58,17 @@ class Dataset(BaseDataset[Batch]):
             image = image.resize((int(w / self._rescale), int(h / self._rescale)))
             scale *= self._rescale
 
+    def _level_tiles(self, w: int, h: int) -> list[tuple[int, int, float, int, int]]:
+        """Size-only twin of ``_partitions``: (level_w, level_h, scale, x, y) in the same order."""
+        out, scale = [], 1.0
+        while True:
+            tiles = list(itertools.product(self._partition(w), self._partition(h)))
+            if not tiles:
+                return out
+            out.extend((w, h, scale, x, y) for x, y in tiles)
+            w, h = int(w / self._rescale), int(h / self._rescale)
+            scale *= self._rescale
+
     def _block(self, image: PIL.Image.Image, x: int, y: int) -> torch.Tensor:
         return self.transforms.transform(image.crop((x, y, x + self._r, y + self._r)))
 
@@ -69,6 +80,12 @@ class Dataset(BaseDataset[Batch]):
         # reference blocks.py:89-109.  Block 0 = whole image; its bbox is (x, y, side, side) —
         # NOT xyxy — a quirk of the reference that the consumer inherits, reproduced verbatim.
         w, h = image.size
+        if self._device_preprocess:
+            # index math only; the pyramid and the crops are produced on the GPU (Validator._encode)
+            bboxes = [((w - h) / 2, 0, h, h) if w > h else (0, (h - w) / 2, w, w)]
+            for _, _, scale, x, y in self._level_tiles(w, h):
+                bboxes.append(self._bbox(scale, x, y))
+            return Batch(output, image_to_u8(image), torch.tensor(bboxes))
         blocks = [self.transforms.transform(image)]
         bboxes: list[tuple] = [((w - h) / 2, 0, h, h) if w > h else (0, (h - w) / 2, w, w)]
         for level, scale, x, y in self._partitions(image):
@@ -89,15 +106,38 @@ class Validator(BaseValidator[Batch]):
         return clip.load_default(False)
 
     def _n_crops(self, batch: Batch) -> int:
-        return batch.blocks.shape[0]
+        return batch.bboxes.shape[0]
+
+    def _device_blocks(self, image_u8: torch.Tensor) -> torch.Tensor:
+        """Blocks of one image on the GPU: block 0 = preprocess(whole image); then per pyramid level
+        exact 224x224 crops of the level image, levels chained by Pillow-exact resizes."""
+        ds = self._dataloader.dataset
+        v = self._model.visual
+        level = image_u8.to(self._device, non_blocking=True)
+        h, w = level.shape[:2]
+        out = [v.crop_resize_normalize(level, [(0, 0, w, h)], out_dtype=torch.float16)]
+        r = ds._r
+        while True:
+            tiles = list(itertools.product(ds._partition(w), ds._partition(h)))
+            if not tiles:
+                break
+            out.append(v.crop_normalize(level, [(x, y, x + r, y + r) for x, y in tiles],
+                                        out_dtype=torch.float16))
+            w, h = int(w / ds._rescale), int(h / ds._rescale)
+            level = v.resize_u8(level, (w, h))
+        return torch.cat(out)
 
     def _encode(self, batches: list[Batch]) -> list[dict]:
         # reference _run_iter (blocks.py:125-135), crops of several images in one encoder pass
-        blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
+        if batches[0].blocks.dtype == torch.uint8:
+            blocks = torch.cat([self._device_blocks(b.blocks) for b in batches])
+            counts = [b.bboxes.shape[0] for b in batches]
+        else:
+            blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
+            counts = [b.blocks.shape[0] for b in batches]
         emb = self._model.encode_image(blocks, normalize=True, out_dtype=torch.float16).cpu()
         out, i = [], 0
-        for b in batches:
-            k = b.blocks.shape[0]
+        for b, k in zip(batches, counts):
             out.append(dict(embeddings=emb[i:i + k].clone(), bboxes=b.bboxes.half()))
             i += k
         return out

@@ -10,7 +10,7 @@ import torch
 
 from .. import clip
 from ..config import Config
-from .base import BaseDataset, BaseValidator
+from .base import BaseDataset, BaseValidator, image_to_u8
 
 
 class Batch(NamedTuple):
@@ -21,6 +21,8 @@ class Batch(NamedTuple):
 class Dataset(BaseDataset[Batch]):
 
     def _preprocess(self, id_: int, output: pathlib.Path, image: PIL.Image.Image) -> Batch:
+        if self._device_preprocess:
+            return Batch(output, image_to_u8(image))  # resize / crop / normalise run on the GPU
         image = self.transforms.transform(image)
         return Batch(output, image)
 
@@ -39,7 +41,18 @@ class Validator(BaseValidator[Batch]):
     def _encode(self, batches: list[Batch]) -> list[torch.Tensor]:
         # reference _run_iter (globals.py:49-60): encode_image -> F.normalize -> squeeze -> .half(),
         # here for a whole batch of images with normalise + fp16 cast fused into the head kernel
-        images = torch.stack([b.image for b in batches]).to(self._device, non_blocking=True)
+        if batches[0].image.dtype == torch.uint8:
+            # device preprocessing: one uint8 HWC upload per image, Pillow-exact resize on the GPU
+            squash = getattr(self._dataloader.dataset.transform, 'squash', False)
+            crops = []
+            for b in batches:
+                h, w = b.image.shape[:2]
+                crops.append(self._model.visual.crop_resize_normalize(
+                    b.image.to(self._device, non_blocking=True), [(0, 0, w, h)], squash=squash,
+                    out_dtype=torch.float16))
+            images = torch.cat(crops)
+        else:
+            images = torch.stack([b.image for b in batches]).to(self._device, non_blocking=True)
         emb = self._model.encode_image(images, normalize=True, out_dtype=torch.float16).cpu()
         return [emb[i].clone() for i in range(len(batches))]
 

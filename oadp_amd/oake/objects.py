@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .. import clip
 from ..config import Config
 from ..store import Store
-from .base import BaseDataset, BaseValidator
+from .base import BaseDataset, BaseValidator, image_to_u8
 
 
 class Batch(NamedTuple):
@@ -31,6 +31,7 @@ class Batch(NamedTuple):
     bboxes: torch.Tensor
     objectness: torch.Tensor
     masks: torch.Tensor
+    crop_boxes: torch.Tensor | None = None  # device preprocessing: expanded boxes, `objects` = uint8 image
 
 
 class ExpandMode(enum.Enum):
@@ -107,6 +108,13 @@ class COCODataset(BaseDataset[Batch]):
         bboxes = self._expand(proposals, torch.tensor(image.size))
         foregrounds = proposals - torch.cat([bboxes[:, :2], bboxes[:, :2]], dim=1)
 
+        if self._device_preprocess:
+            # masks (index math) here; the crops are cut + resized on the GPU from the uint8 image.
+            # `objects` carries the image, `crop_boxes` the expanded boxes (PIL crop semantics).
+            masks = [self._mask(tuple(fg), tuple(box))
+                     for fg, box in zip(foregrounds.tolist(), bboxes.tolist())]
+            masks_t = torch.cat(masks) if masks else torch.zeros(0, 1, self._grid, self._grid)
+            return Batch(output, image_to_u8(image), proposals, objectness, masks_t, bboxes)
         objects, masks = [], []
         for fg, box in zip(foregrounds.tolist(), bboxes.tolist()):
             objects.append(self._object(image, box))
@@ -159,12 +167,19 @@ class Validator(BaseValidator[Batch]):
         return model, preprocess
 
     def _n_crops(self, batch: Batch) -> int:
-        return batch.objects.shape[0]
+        return batch.bboxes.shape[0]
 
     def _encode(self, batches: list[Batch]) -> list[dict]:
         # reference _run_iter (objects.py:316-338): mini-batches of `mini_batch_size` crops through
         # model.visual(objects, masks), normalise, cat, .half() x3
-        objects = torch.cat([b.objects for b in batches])
+        if batches[0].crop_boxes is not None:
+            # device preprocessing: preprocess(image.crop(box)) for all proposals of an image in
+            # three kernel launches, bit-exact with the PIL path
+            objects = torch.cat([self._model.visual.crop_resize_normalize(
+                b.objects.to(self._device, non_blocking=True), b.crop_boxes, out_dtype=torch.float16)
+                for b in batches])
+        else:
+            objects = torch.cat([b.objects for b in batches])
         masks = torch.cat([b.masks for b in batches])
         embs = []
         for i in range(math.ceil(objects.shape[0] / self._mini_batch_size)):
@@ -175,7 +190,7 @@ class Validator(BaseValidator[Batch]):
         emb = torch.cat(embs) if embs else torch.zeros(0, 512, dtype=torch.float16)
         out, i = [], 0
         for b in batches:
-            n = b.objects.shape[0]
+            n = b.bboxes.shape[0]
             out.append(dict(embeddings=emb[i:i + n].clone(), bboxes=b.bboxes.half(),
                             objectness=b.objectness.half()))
             i += n

@@ -81,6 +81,45 @@ def test_globals_blocks_objects_files_match_oracle(cuda, tmp_path):
         _cmp(g['embeddings'], r['embeddings'])
 
 
+def test_device_preprocess_matches_host_preprocess(cuda, tmp_path, monkeypatch):
+    """device_preprocess=True (uint8 upload, GPU crop / Pillow-exact resize / normalise) writes the
+    same .pth payloads, bit for bit, as the PIL path of the reference's DataLoader workers."""
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    coco = _synth.make_coco(tmp_path / 'coco', SIZES + [(1000, 700)])
+    sd = synthetic_state_dict(**_synth.TINY)
+
+    def run(cls, tag, dev_pre, surgery=False, dataset=None, validator=None):
+        out = tmp_path / f'{tag}_{int(dev_pre)}'
+        model, pre = clip.load(sd, max_batch=64)
+        if surgery:
+            v = model.visual
+            v.positional_embedding = v.interpolate_positional_embedding((v.grid * 2,) * 2)
+            v.grid *= 2
+            v.conv1.stride = tuple(s // 2 for s in v.conv1.stride)
+            v.conv1.padding = ((v.patch_size - 1) // 2,) * 2
+            v.object_stream = True
+        dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(out),
+                                 transform=pre, device_preprocess=dev_pre, **(dataset or {})), num_workers=0)
+        cls(tag, model, dataloader=dl, device='cuda:0', **(validator or {})).run()
+        return out
+
+    for cls, tag, kw in [
+            (globals_.Validator, 'g', {}),
+            (blocks.Validator, 'b', dict(validator=dict(batch_size=64))),
+            (objects.Validator, 'o', dict(surgery=True, dataset=dict(
+                type='COCODataset', proposal_file=coco['proposal_file'], proposal_sorted=True),
+                validator=dict(mini_batch_size=16, batch_size=32)))]:
+        host, dev = run(cls, tag, False, **kw), run(cls, tag, True, **kw)
+        for id_ in coco['ids']:
+            a, b = torch.load(host / f'{id_:012d}.pth', 'cpu'), torch.load(dev / f'{id_:012d}.pth', 'cpu')
+            if isinstance(a, dict):
+                assert a.keys() == b.keys()
+                for k in a:
+                    assert torch.equal(a[k], b[k]), (tag, id_, k)
+            else:
+                assert torch.equal(a, b), (tag, id_)
+
+
 def test_crop_normalize_kernel_is_bit_exact(cuda, lib):
     """GPU crop + ToTensor + Normalize of level-0 blocks == the host transform, bit for bit."""
     from oadp_amd.clip.preprocess import CLIP_MEAN, CLIP_STD

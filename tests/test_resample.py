@@ -1,0 +1,40 @@
+"""Pin the resampler restatement (oracle/resample_ref.py) against Pillow itself, bit for bit."""
+import numpy as np
+import PIL.Image
+import pytest
+
+from oracle import resample_ref
+
+
+def _img(w, h, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    # add smooth structure + saturated regions so clipping and antialiasing both matter
+    yy, xx = np.mgrid[0:h, 0:w]
+    base[..., 0] = np.clip(base[..., 0].astype(int) // 2 + (xx * 255 // max(w - 1, 1)) // 2, 0, 255)
+    base[:h // 5, :w // 5] = 255
+    base[-h // 6:, -w // 6:] = 0
+    return base
+
+
+@pytest.mark.parametrize('w,h,ow,oh', [(640, 480, 426, 320), (426, 320, 284, 213), (100, 80, 224, 224),
+                                       (37, 53, 224, 224), (500, 375, 298, 224), (1700, 1134, 1133, 756),
+                                       (224, 300, 224, 224), (301, 299, 225, 224), (9, 7, 224, 224)])
+def test_resize_matches_pillow(w, h, ow, oh):
+    img = _img(w, h, w * 31 + h)
+    ref = np.asarray(PIL.Image.fromarray(img).resize((ow, oh), PIL.Image.BICUBIC))
+    got = resample_ref.resize_ref(img, ow, oh)
+    assert np.array_equal(got, ref)
+
+
+def test_default_resize_filter_is_bicubic():
+    img = _img(90, 60, 1)
+    a = np.asarray(PIL.Image.fromarray(img).resize((60, 40)))
+    assert np.array_equal(a, resample_ref.resize_ref(img, 60, 40))
+
+
+def test_crop_matches_pillow():
+    img = _img(120, 90, 5)
+    pil = PIL.Image.fromarray(img)
+    for box in [(0.5, 1.5, 40.5, 60.5), (-10.2, -5.7, 50.1, 44.4), (100, 70, 140, 110), (2.5, 3.5, 4.5, 6.5)]:
+        assert np.array_equal(resample_ref.crop_ref(img, box), np.asarray(pil.crop(box)))
