@@ -50,6 +50,8 @@ def main() -> None:
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--dtype', choices=['f16', 'bf16'], default=os.environ.get('OAKE_DTYPE', 'f16'))
+    ap.add_argument('--residual', choices=['f16', 'f32'], default='f16',
+                    help='residual-stream element type (f16 = compute dtype, as the reference GPU model)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
@@ -72,7 +74,8 @@ def main() -> None:
         _lib.load().oake_debug_set_attention_variant(int(os.environ['OAKE_ATTN_VARIANT']))
     cdt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
     sd = synthetic_state_dict()
-    model, _ = clip.load(sd, compute_dtype=cdt, max_batch=args.batch)
+    model, _ = clip.load(sd, compute_dtype=cdt, max_batch=args.batch,
+                         residual_dtype=torch.float32 if args.residual == 'f32' else None)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(args.batch, 3, 224, 224, generator=g, device=dev)  # resident in HBM
 

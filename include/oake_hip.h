@@ -89,12 +89,13 @@ typedef struct oake_config {
   int32_t embed_dim;
   int32_t compute_dtype;
   int32_t max_batch;      /* workspace is sized for this many crops per internal pass */
-  int32_t reserved;
+  int32_t residual_dtype; /* element type of the residual stream x: == compute_dtype (default; the
+                             reference's GPU model keeps x in fp16 too) or OAKE_F32 */
 } oake_config;
 
 OAKE_API uint32_t oake_abi_version(void);
 
-/* Fill *cfg with ViT-B/32 defaults (stride 32, padding 0, f16, max_batch 256). */
+/* Fill *cfg with ViT-B/32 defaults (stride 32, padding 0, f16 compute + f16 residual, max_batch 256). */
 OAKE_API void oake_default_config(oake_config* cfg);
 
 /* Create a handle on HIP device `device`.  Allocates weights + workspace. */
@@ -205,8 +206,9 @@ OAKE_API int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bi
 /* C16[m,n] = (quick_gelu?)(A * W^T + bias) stored in the 16-bit operand type (n % 8 == 0). */
 OAKE_API int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, void* d_c,
                       int m, int n, int k, int dtype16, int gelu, void* stream);
-/* y = LayerNorm(x) over last dim `c` (eps 1e-5), x fp32 [rows,c] -> y 16-bit [rows,c]. */
-OAKE_API int oake_debug_layernorm(const float* d_x, const float* d_gamma, const float* d_beta,
+/* y = LayerNorm(x) over last dim `c` (eps 1e-5), x [rows,c] of x_dtype (OAKE_F32 or dtype16)
+ * -> y 16-bit [rows,c]. */
+OAKE_API int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, const float* d_beta,
                          void* d_y, int rows, int c, int dtype16, void* stream);
 /* Multi-head self-attention on packed qkv [n*l, 3*heads*64] (q pre-scaled), -> [n*l, heads*64]. */
 OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads,
@@ -218,8 +220,8 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
 OAKE_API int oake_debug_set_attention_variant(int variant);
 /* GEMM configuration: -1 = automatic per shape, 0..4 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
-/* Debug: device buffer of 64*2*8*4 uint64 receiving per-tile cycle stamps of the production GEMM
- * (entry, tile start, epilogue start, epilogue end), or NULL to disable. */
+/* Debug: device buffer of 4608 uint64 receiving per-tile cycle stamps of the production GEMM
+ * (entry, tile start, epilogue start, epilogue end; then per-block wall-clock entry/exit), or NULL. */
 OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
 
 #ifdef __cplusplus

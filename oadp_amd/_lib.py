@@ -15,7 +15,7 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / 'liboake_hip.so'
 class OakeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'image_size', 'patch_size', 'stride', 'padding', 'width', 'layers', 'heads', 'mlp_dim',
-        'embed_dim', 'compute_dtype', 'max_batch', 'reserved')]
+        'embed_dim', 'compute_dtype', 'max_batch', 'residual_dtype')]
 
 
 class ProfileEntry(C.Structure):
@@ -47,7 +47,7 @@ SIGNATURES = {
     'oake_profile_reset': (_I, [_VP]),
     'oake_debug_gemm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_gemm16': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
-    'oake_debug_layernorm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    'oake_debug_layernorm': (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),
     'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
     'oake_debug_set_attention_variant': (_I, [_I]),

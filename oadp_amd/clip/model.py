@@ -56,7 +56,8 @@ def _infer_arch(sd: Mapping[str, torch.Tensor]) -> dict:
 class VisionTransformer:
 
     def __init__(self, state_dict: Mapping[str, torch.Tensor], *, compute_dtype=torch.float16,
-                 max_batch: int = 256, device: int | None = None) -> None:
+                 residual_dtype: torch.dtype | None = None, max_batch: int = 256,
+                 device: int | None = None) -> None:
         sd = {k: v.detach().to('cpu', torch.float32).contiguous()
               for k, v in state_dict.items() if k.startswith(VISION_PREFIX)}
         self._sd = sd
@@ -73,6 +74,8 @@ class VisionTransformer:
         self.positional_embedding = sd['visual.positional_embedding']
         self.object_stream = False  # set by objects-mode surgery (replaces the reference's Hooks)
         self.compute_dtype = compute_dtype
+        # residual stream x: the compute dtype (as the reference's fp16 GPU model) or float32
+        self.residual_dtype = residual_dtype or compute_dtype
         self.max_batch = max_batch
         self.device = device
         self._lib = _lib.load()
@@ -114,7 +117,7 @@ class VisionTransformer:
         pos = self.positional_embedding
         pos = pos.data if isinstance(pos, torch.nn.Parameter) else pos
         key = (device_index, stride, pad, pos.data_ptr(), tuple(pos.shape), self.compute_dtype,
-               self.max_batch)
+               self.residual_dtype, self.max_batch)
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self.close()
@@ -126,6 +129,7 @@ class VisionTransformer:
         cfg.width, cfg.layers, cfg.heads = self.width, self.layers, self.heads
         cfg.mlp_dim, cfg.embed_dim = self.mlp_dim, self.output_dim
         cfg.compute_dtype = _TORCH2OAKE[self.compute_dtype]
+        cfg.residual_dtype = _TORCH2OAKE[self.residual_dtype]
         cfg.max_batch = self.max_batch
         h = C.c_void_p()
         _lib.check(lib, None, lib.oake_create(C.byref(cfg), device_index, C.byref(h)), 'oake_create')

@@ -60,6 +60,7 @@ struct oake_handle {
   int device = 0;
   int grid = 0, tokens = 0, p2 = 0, kpatch = 0;
   int dt16 = DT_F16;
+  int xdt = DT_F32;           // residual-stream element type: DT_F32 or dt16
   std::string err;
 
   // weights
@@ -75,7 +76,7 @@ struct oake_handle {
 
   // workspace (sized for cfg.max_batch crops)
   void* a_patch = nullptr;
-  float* x = nullptr;
+  void* x = nullptr;          // residual stream [B*L, C] of type xdt
   void *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr;
   float* y = nullptr;
   float* e32 = nullptr;       // [B, embed] fp32 head projection
@@ -222,6 +223,7 @@ void oake_default_config(oake_config* c) {
   c->embed_dim = 512;
   c->compute_dtype = OAKE_F16;
   c->max_batch = 256;
+  c->residual_dtype = OAKE_F16;
 }
 
 const char* oake_last_error(const oake_handle* h) {
@@ -275,6 +277,8 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   if (c.compute_dtype != OAKE_F16 && c.compute_dtype != OAKE_BF16)
     return bad("compute_dtype must be OAKE_F16 or OAKE_BF16");
   if (c.layers <= 0 || c.max_batch <= 0) return bad("layers and max_batch must be positive");
+  if (c.residual_dtype != OAKE_F32 && c.residual_dtype != c.compute_dtype)
+    return bad("residual_dtype must be OAKE_F32 or equal to compute_dtype");
 
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) {
@@ -285,6 +289,7 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   h->cfg = c;
   h->device = device;
   h->dt16 = c.compute_dtype;
+  h->xdt = c.residual_dtype == OAKE_F32 ? DT_F32 : c.compute_dtype;
   h->grid = (c.image_size + 2 * c.padding - c.patch_size) / c.stride + 1;
   h->p2 = h->grid * h->grid;
   h->tokens = h->p2 + 1;
@@ -322,7 +327,7 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   A((void**)&h->stage, h->stage_elems * 4);
   // workspace
   A(&h->a_patch, B * h->p2 * h->kpatch * e16());
-  A((void**)&h->x, B * L * C * 4);
+  A(&h->x, B * L * C * (h->xdt == DT_F32 ? 4 : 2));
   A(&h->xn, B * L * C * e16());
   A(&h->qkv, B * L * 3 * C * e16());
   A(&h->att, B * L * C * e16());
@@ -452,9 +457,10 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   GemmArgs a{};
   a.A = h->a_patch; a.W = h->conv_w; a.bias = nullptr; a.out = h->x;
   a.M = nb * h->p2; a.N = C; a.K = h->kpatch; a.ldo = C; a.pos = h->pos; a.P2 = h->p2; a.L = L;
-  RUN(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0, launch_gemm(h->dt16, EPI_PATCH, a, s));
+  RUN(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0,
+      launch_gemm(h->dt16, h->xdt == DT_F32 ? EPI_PATCH : EPI_PATCH16, a, s));
   RUN(h, s, "embed_ln_pre", 0.0, 2.0 * nb * L * C * 4,
-      launch_embed_ln_pre(h->x, h->cls, h->pos, h->lnpre_g, h->lnpre_b, nb, L, C, s));
+      launch_embed_ln_pre(h->x, h->xdt, h->cls, h->pos, h->lnpre_g, h->lnpre_b, nb, L, C, s));
   return OAKE_OK;
 }
 
@@ -465,20 +471,20 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   RUN(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
       launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, s));
   int rc;
-  if ((rc = gemm(h, s, "gemm_out_proj", EPI_RESID, h->att, w.out_w, w.out_b, h->x, T, C, C, C))) return rc;
+  if ((rc = gemm(h, s, "gemm_out_proj", h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16, h->att, w.out_w, w.out_b, h->x, T, C, C, C))) return rc;
   RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-      launch_layernorm(h->dt16, h->x, C, w.ln2_g, w.ln2_b, h->xn, T, C, s));
+      launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln2_g, w.ln2_b, h->xn, T, C, s));
   if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU, h->xn, w.fc_w, w.fc_b, h->hbuf, T, F, C, F))) return rc;
-  if ((rc = gemm(h, s, "gemm_c_proj", EPI_RESID, h->hbuf, w.proj_w, w.proj_b, h->x, T, C, F, C))) return rc;
+  if ((rc = gemm(h, s, "gemm_c_proj", h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16, h->hbuf, w.proj_w, w.proj_b, h->x, T, C, F, C))) return rc;
   return OAKE_OK;
 }
 
 // ln_post over `nb` rows (x + i*row_stride) -> @ proj -> optional L2 normalise -> out
-int head(oake_handle* h, hipStream_t s, const float* x, long row_stride, void* outp, int out_dtype,
-         int normalize, int nb) {
+int head(oake_handle* h, hipStream_t s, const void* x, int x_dtype, long row_stride, void* outp,
+         int out_dtype, int normalize, int nb) {
   const int C = h->cfg.width, E = h->cfg.embed_dim;
   RUN(h, s, "head_ln_post", 0.0, (double)nb * C * 6,
-      launch_layernorm(h->dt16, x, row_stride, h->lnpost_g, h->lnpost_b, h->yn, nb, C, s));
+      launch_layernorm(h->dt16, x, x_dtype, row_stride, h->lnpost_g, h->lnpost_b, h->yn, nb, C, s));
   int rc;
   if ((rc = gemm(h, s, "gemm_head_proj", EPI_F32_BIAS, h->yn, h->proj, nullptr, h->e32, nb, E, C, E)))
     return rc;
@@ -585,12 +591,12 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
     for (int l = 0; l < c.layers; ++l) {
       const LayerW& w = h->layers[l];
       RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-          launch_layernorm(h->dt16, h->x, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
+          launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
       if ((rc = gemm(h, s, "gemm_qkv", EPI_T16_BIAS, h->xn, w.in_w, w.in_b, h->qkv, T, 3 * C, C, 3 * C)))
         return rc;
       if ((rc = main_block_tail(h, s, w, nb))) return rc;
     }
-    if ((rc = head(h, s, h->x, (long)L * C, outp, out_dtype, normalize, nb))) return rc;
+    if ((rc = head(h, s, h->x, h->xdt, (long)L * C, outp, out_dtype, normalize, nb))) return rc;
   }
   return OAKE_OK;
 }
@@ -626,13 +632,13 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
     char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
     if ((rc = patch_embed(h, s, imgs, in_dtype, nb))) return rc;
     // Hooks.transformer_forward_pre (objects.py:215-221): y = x[[0]] (after ln_pre)
-    RUN(h, s, "copy_cls", 0.0, 2.0 * nb * C * 4, launch_copy_cls(h->x, h->y, nb, L, C, s));
+    RUN(h, s, "copy_cls", 0.0, 2.0 * nb * C * 4, launch_copy_cls(h->x, h->xdt, h->y, nb, L, C, s));
     for (int l = 0; l < c.layers; ++l) {
       const LayerW& w = h->layers[l];
       const bool last = (l == c.layers - 1);
       // ln_1 + in-proj of the main stream: k/v of patch rows serve both streams (Appendix C #1)
       RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-          launch_layernorm(h->dt16, h->x, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
+          launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
       if (!last) {
         if ((rc = gemm(h, s, "gemm_qkv", EPI_T16_BIAS, h->xn, w.in_w, w.in_b, h->qkv, T, 3 * C, C, 3 * C)))
           return rc;
@@ -645,7 +651,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       }
       // object-token stream (Hooks.residual_attention_block_forward_pre, objects.py:223-247)
       RUN(h, s, "layernorm_y", 0.0, (double)nb * C * 6,
-          launch_layernorm(h->dt16, h->y, C, w.ln1_g, w.ln1_b, h->yn, nb, C, s));
+          launch_layernorm(h->dt16, h->y, DT_F32, C, w.ln1_g, w.ln1_b, h->yn, nb, C, s));
       if ((rc = gemm(h, s, "gemm_qkv_y", EPI_T16_BIAS, h->yn, w.in_w, w.in_b, h->qkv_y, nb, 3 * C, C, 3 * C)))
         return rc;
       RUN(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
@@ -654,7 +660,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       if ((rc = gemm(h, s, "gemm_out_proj_y", EPI_RESID, h->att_y, w.out_w, w.out_b, h->y, nb, C, C, C)))
         return rc;
       RUN(h, s, "layernorm_y", 0.0, (double)nb * C * 6,
-          launch_layernorm(h->dt16, h->y, C, w.ln2_g, w.ln2_b, h->yn, nb, C, s));
+          launch_layernorm(h->dt16, h->y, DT_F32, C, w.ln2_g, w.ln2_b, h->yn, nb, C, s));
       if ((rc = gemm(h, s, "gemm_c_fc_y", EPI_T16_GELU, h->yn, w.fc_w, w.fc_b, h->h_y, nb, F, C, F)))
         return rc;
       if ((rc = gemm(h, s, "gemm_c_proj_y", EPI_RESID, h->h_y, w.proj_w, w.proj_b, h->y, nb, C, F, C)))
@@ -663,7 +669,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       // y in Hooks.transformer_forward, objects.py:249-258)
       if (!last && (rc = main_block_tail(h, s, w, nb))) return rc;
     }
-    if ((rc = head(h, s, h->y, (long)C, outp, out_dtype, normalize, nb))) return rc;
+    if ((rc = head(h, s, h->y, DT_F32, (long)C, outp, out_dtype, normalize, nb))) return rc;
   }
   return OAKE_OK;
 }
@@ -795,9 +801,9 @@ int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, voi
                          reinterpret_cast<hipStream_t>(stream)));
 }
 
-int oake_debug_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, void* d_y,
-                         int rows, int c, int dtype16, void* stream) {
-  return dbg(launch_layernorm(dtype16, d_x, c, d_gamma, d_beta, d_y, rows, c,
+int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, const float* d_beta,
+                         void* d_y, int rows, int c, int dtype16, void* stream) {
+  return dbg(launch_layernorm(dtype16, d_x, x_dtype, c, d_gamma, d_beta, d_y, rows, c,
                               reinterpret_cast<hipStream_t>(stream)));
 }
 

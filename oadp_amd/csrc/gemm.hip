@@ -65,7 +65,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 template <int EPI>
 struct EpiTraits {
   // 16-bit outputs use the paired column mapping (see header comment)
-  static constexpr bool kPaired = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU);
+  static constexpr bool kPaired = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU ||
+                                   EPI == EPI_RESID16 || EPI == EPI_PATCH16);
+  // pure stores (no read-modify-write): the persistent kernel may hold them back and trickle them
+  static constexpr bool kTrickle = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU);
 };
 
 // Column (relative to the wave's TN-column block) held by LDS row l = 16*ni + rho of that block.
@@ -128,17 +131,42 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
   if (PAIRED) {
     static_assert(!PAIRED || NI % 2 == 0, "paired mapping needs an even number of column tiles");
     constexpr int NP = NI / 2;
+    typedef typename T16<T>::vec8 vec8;
     float4 b0[NP], b1[NP];
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       const int n = nwave + 32 * t + 8 * g;
-      const bool ok = ep.bias != nullptr && (FULL || n < N);
+      const bool ok = EPI != EPI_PATCH16 && ep.bias != nullptr && (FULL || n < N);
       b0[t] = ok ? *reinterpret_cast<const float4*>(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       b1[t] = ok ? *reinterpret_cast<const float4*>(ep.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = mbase + mi * 16;
+      const bool mok = FULL || m < M;
+      size_t orow = (size_t)m;
+      const float* posrow = nullptr;
+      if (EPI == EPI_PATCH16) {
+        const int img = m / ep.P2;
+        const int p = m - img * ep.P2;
+        orow = (size_t)img * ep.L + 1 + p;
+        posrow = ep.pos + (size_t)(1 + p) * N;
+      }
+      T* orow_ptr = reinterpret_cast<T*>(ep.out) + orow * ep.ldo;
+      // this row's residual (8 x 16-bit) / pos-emb (8 x fp32) loads first, then the stores
+      vec8 xr[NP];
+      float4 p0[NP], p1[NP];
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        const int n = nwave + 32 * t + 8 * g;
+        const bool ok = FULL || (mok && n < N);
+        if (EPI == EPI_RESID16) {
+          if (ok) xr[t] = *reinterpret_cast<const vec8*>(orow_ptr + n);
+        } else if (EPI == EPI_PATCH16) {
+          p0[t] = ok ? *reinterpret_cast<const float4*>(posrow + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          p1[t] = ok ? *reinterpret_cast<const float4*>(posrow + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
 #pragma unroll
       for (int t = 0; t < NP; ++t) {
         const int n = nwave + 32 * t + 8 * g;
@@ -147,7 +175,7 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
           acc[mi][2 * t] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[mi][2 * t + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (!FULL && !(m < M && n < N)) continue;
+        if (!FULL && !(mok && n < N)) continue;
         lo[0] += b0[t].x; lo[1] += b0[t].y; lo[2] += b0[t].z; lo[3] += b0[t].w;
         hi[0] += b1[t].x; hi[1] += b1[t].y; hi[2] += b1[t].z; hi[3] += b1[t].w;
         if (EPI == EPI_T16_GELU) {
@@ -156,11 +184,19 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
             lo[r] = quick_gelu(lo[r]);
             hi[r] = quick_gelu(hi[r]);
           }
+        } else if (EPI == EPI_RESID16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            lo[r] += to32<T>(xr[t][r]);
+            hi[r] += to32<T>(xr[t][4 + r]);
+          }
+        } else if (EPI == EPI_PATCH16) {
+          lo[0] += p0[t].x; lo[1] += p0[t].y; lo[2] += p0[t].z; lo[3] += p0[t].w;
+          hi[0] += p1[t].x; hi[1] += p1[t].y; hi[2] += p1[t].z; hi[3] += p1[t].w;
         }
-        const uint2 p0 = pack4<T>(lo[0], lo[1], lo[2], lo[3]);
-        const uint2 p1 = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
-        T* o = reinterpret_cast<T*>(ep.out) + (size_t)m * ep.ldo + n;
-        *reinterpret_cast<uint4*>(o) = make_uint4(p0.x, p0.y, p1.x, p1.y);
+        const uint2 q0 = pack4<T>(lo[0], lo[1], lo[2], lo[3]);
+        const uint2 q1 = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(orow_ptr + n) = make_uint4(q0.x, q0.y, q1.x, q1.y);
       }
     }
     return;
@@ -537,8 +573,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 
   // pending (packed, not yet stored) 16-bit tile: see tile_pack_paired
   constexpr int MI0 = 1;  // rows stored immediately at tile end (register budget, see tile_pack_paired)
-  constexpr int NPEND = PAIRED ? (MI - MI0) * (NI / 2) : 1;
-  uint4 pend[PAIRED ? MI - MI0 : 1][PAIRED ? NI / 2 : 1];
+  constexpr bool TRICKLE = EpiTraits<EPI>::kTrickle;
+  constexpr int NPEND = TRICKLE ? (MI - MI0) * (NI / 2) : 1;
+  uint4 pend[TRICKLE ? MI - MI0 : 1][TRICKLE ? NI / 2 : 1];
   T* pend_ptr = nullptr;  // lane's address of the tile's first row-block (mi = 0, t = 0)
   int pend_next = NPEND;  // next pending piece to store (NPEND = none)
 #define OAKE_STORE_PEND(i_)                                                                  \
@@ -546,6 +583,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
                             ((i_) % (NI / 2)) * 32) = pend[(i_) / (NI / 2)][(i_) % (NI / 2)]
 
   const unsigned long long t_entry = tmap.trace ? __builtin_readcyclecounter() : 0;
+  if (tmap.trace != nullptr && tid == 0) tmap.trace[4096 + blockIdx.x * 2] = wall_clock64();
   OAKE_BAR();            // b0
   if (late) OAKE_BAR();  // group 1 runs one phase behind group 0 (and the DMA waves)
   int c_buf = 0, c_kt = 0, c_tile = 0;
@@ -558,7 +596,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     OAKE_BAR();
     OAKE_LOAD_FRAGS(c_buf, koff1);
     OAKE_LGKM0();
-    if constexpr (PAIRED) if (pend_next < NPEND) {
+    if constexpr (TRICKLE) if (pend_next < NPEND) {
       // one trickled store per K-tile, in this wave's load phase (static register indices: a
       // runtime-indexed register array would live in scratch)
       OAKE_PIN();
@@ -579,7 +617,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       const bool interior = m0 + BM <= M && n0 + BN <= N;
       OAKE_PIN();
       const unsigned long long t_ep = tmap.trace ? __builtin_readcyclecounter() : 0;
-      if constexpr (PAIRED) {
+      if constexpr (TRICKLE) {
         // flush what is still pending from the previous tile (only when a tile has < NPEND K-tiles)
 #pragma unroll
         for (int i = 0; i < NPEND; ++i)
@@ -587,7 +625,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
         pend_next = NPEND;
       }
       bool deferred = false;
-      if constexpr (PAIRED) {
+      if constexpr (TRICKLE) {
         if (interior && c_tile < my_tiles) {
           pend_ptr = reinterpret_cast<T*>(ep.out) + (size_t)(m0 + wm * TM + frow) * ep.ldo + n0 +
                      wn * TN + 8 * fg;
@@ -619,6 +657,10 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     tile_origin(tmap, xb + xslot + (my_tiles - 1) * per_xcd, BM, BN, m0, n0);
     tile_epilogue<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, false,
                                   m0 + BM <= M && n0 + BN <= N);
+  }
+  if (tmap.trace != nullptr && tid == 256) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    tmap.trace[4096 + blockIdx.x * 2 + 1] = wall_clock64();
   }
 #undef OAKE_STORE_PEND
 #undef OAKE_LOAD_FRAGS
@@ -722,6 +764,8 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_T16_GELU: return launch_variant<T, EPI_T16_GELU>(v, a, s);
     case EPI_RESID: return launch_variant<T, EPI_RESID>(v, a, s);
     case EPI_PATCH: return launch_variant<T, EPI_PATCH>(v, a, s);
+    case EPI_RESID16: return launch_variant<T, EPI_RESID16>(v, a, s);
+    case EPI_PATCH16: return launch_variant<T, EPI_PATCH16>(v, a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -731,7 +775,8 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
   if (a.K % BK != 0 || a.N % 4 != 0 || a.ldo % 4 != 0) return hipErrorInvalidValue;
-  if ((epi == EPI_T16_BIAS || epi == EPI_T16_GELU) && (a.N % 8 != 0 || a.ldo % 8 != 0))
+  if ((epi == EPI_T16_BIAS || epi == EPI_T16_GELU || epi == EPI_RESID16 || epi == EPI_PATCH16) &&
+      (a.N % 8 != 0 || a.ldo % 8 != 0))
     return hipErrorInvalidValue;
   if (dtype16 == DT_F16) return launch_epi<f16_t>(epi, a, s);
   if (dtype16 == DT_BF16) return launch_epi<bf16_t>(epi, a, s);

@@ -14,7 +14,9 @@ enum GemmEpi {
   EPI_T16_BIAS = 1,   // out T16 [M,ldo] = acc + bias                  (QKV in-proj)
   EPI_T16_GELU = 2,   // out T16 [M,ldo] = quick_gelu(acc + bias)      (MLP c_fc)
   EPI_RESID = 3,      // out fp32 [M,ldo] += acc + bias                (attn out_proj, MLP c_proj)
-  EPI_PATCH = 4       // out fp32 x[(m/P2)*L + 1 + m%P2, :] = acc + pos[1 + m%P2, :]   (conv1)
+  EPI_PATCH = 4,      // out fp32 x[(m/P2)*L + 1 + m%P2, :] = acc + pos[1 + m%P2, :]   (conv1)
+  EPI_RESID16 = 5,    // EPI_RESID on a 16-bit residual stream (read-modify-write in T16)
+  EPI_PATCH16 = 6     // EPI_PATCH writing a 16-bit residual stream
 };
 
 struct GemmArgs {
@@ -33,16 +35,19 @@ struct GemmArgs {
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
 
 // ---- row kernels -------------------------------------------------------------------------
-// y(16-bit)[rows,c] = LN(x fp32 [rows, c]) ; x rows are `x_row_stride` floats apart.
-hipError_t launch_layernorm(int dtype16, const float* x, long x_row_stride, const float* gamma,
-                            const float* beta, void* y, int rows, int c, hipStream_t s);
+// y(16-bit)[rows,c] = LN(x [rows, c]); x is fp32 (x_dtype DT_F32) or the 16-bit type (x_dtype ==
+// dtype16); x rows are `x_row_stride` ELEMENTS apart.  Statistics in fp32 either way.
+hipError_t launch_layernorm(int dtype16, const void* x, int x_dtype, long x_row_stride,
+                            const float* gamma, const float* beta, void* y, int rows, int c,
+                            hipStream_t s);
 
-// x[n*L + t, :] (fp32, in place): t == 0 -> cls + pos[0]; then ln_pre over every row.
-hipError_t launch_embed_ln_pre(float* x, const float* cls, const float* pos, const float* gamma,
-                               const float* beta, int n, int L, int c, hipStream_t s);
+// x[n*L + t, :] (in place, fp32 or 16-bit): t == 0 -> cls + pos[0]; then ln_pre over every row.
+hipError_t launch_embed_ln_pre(void* x, int x_dtype, const float* cls, const float* pos,
+                               const float* gamma, const float* beta, int n, int L, int c,
+                               hipStream_t s);
 
-// y[n, :] = x[n*L + 0, :]  (objects mode: object-token stream starts as the CLS row)
-hipError_t launch_copy_cls(const float* x, float* y, int n, int L, int c, hipStream_t s);
+// y[n, :] (fp32) = x[n*L + 0, :]  (objects mode: object-token stream starts as the CLS row)
+hipError_t launch_copy_cls(const void* x, int x_dtype, float* y, int n, int L, int c, hipStream_t s);
 
 // im2col of NCHW images into the conv1 GEMM A operand [n*G*G, 3*P*P] (16-bit).
 hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, int n, int image,

@@ -32,8 +32,28 @@ __device__ __forceinline__ void ln_stats(const float4 (&v)[kMaxVec], int lane, i
   rstd = rsqrtf(q / (float)c + kLnEps);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long stride,
+// 4 consecutive elements of a row of the residual stream (fp32 or 16-bit) <-> float4
+template <typename TX>
+__device__ __forceinline__ float4 load4(const TX* row, int i4) {
+  if constexpr (sizeof(TX) == 4) {
+    return reinterpret_cast<const float4*>(row)[i4];
+  } else {
+    typedef TX v4 __attribute__((ext_vector_type(4)));
+    const v4 v = __builtin_bit_cast(v4, reinterpret_cast<const uint2*>(row)[i4]);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+}
+template <typename TX>
+__device__ __forceinline__ void store4(TX* row, int i4, float a, float b, float c, float d) {
+  if constexpr (sizeof(TX) == 4) {
+    reinterpret_cast<float4*>(row)[i4] = make_float4(a, b, c, d);
+  } else {
+    reinterpret_cast<uint2*>(row)[i4] = pack4<TX>(a, b, c, d);
+  }
+}
+
+template <typename T, typename TX>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x, long stride,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         T* __restrict__ y, int rows, int c) {
@@ -41,11 +61,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv = c >> 2;
-  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * stride);
+  const TX* xr = x + (size_t)row * stride;
   float4 v[kMaxVec];
 #pragma unroll
   for (int i = 0; i < kMaxVec; ++i)
-    if (lane + 64 * i < nv) v[i] = xr[lane + 64 * i];
+    if (lane + 64 * i < nv) v[i] = load4<TX>(xr, lane + 64 * i);
   float mean, rstd;
   ln_stats(v, lane, nv, c, mean, rstd);
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
@@ -62,7 +82,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // x[n*L + t] in place: t == 0 takes cls + pos[0] (patch rows already carry conv + pos from the
 // EPI_PATCH GEMM epilogue), then ln_pre.
-__global__ __launch_bounds__(256) void embed_ln_pre_kernel(float* __restrict__ x,
+template <typename TX>
+__global__ __launch_bounds__(256) void embed_ln_pre_kernel(TX* __restrict__ x,
                                                            const float* __restrict__ cls,
                                                            const float* __restrict__ pos,
                                                            const float* __restrict__ gamma,
@@ -72,7 +93,7 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(float* __restrict__ x
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv = c >> 2;
-  float4* xr = reinterpret_cast<float4*>(x + (size_t)row * c);
+  TX* xr = x + (size_t)row * c;
   const bool is_cls = (row % L) == 0;
   const float4* c4 = reinterpret_cast<const float4*>(cls);
   const float4* p4 = reinterpret_cast<const float4*>(pos);
@@ -84,7 +105,7 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(float* __restrict__ x
         const float4 a = c4[lane + 64 * i], b = p4[lane + 64 * i];
         v[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
       } else {
-        v[i] = xr[lane + 64 * i];
+        v[i] = load4<TX>(xr, lane + 64 * i);
       }
     }
   float mean, rstd;
@@ -95,20 +116,18 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(float* __restrict__ x
   for (int i = 0; i < kMaxVec; ++i)
     if (lane + 64 * i < nv) {
       const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
-      xr[lane + 64 * i] =
-          make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                      (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      store4<TX>(xr, lane + 64 * i, (v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                 (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
     }
 }
 
-__global__ void copy_cls_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int L,
-                                int c) {
+template <typename TX>
+__global__ void copy_cls_kernel(const TX* __restrict__ x, float* __restrict__ y, int n, int L, int c) {
   const int nv = c >> 2;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)n * nv) return;
   const int img = idx / nv, j = idx % nv;
-  reinterpret_cast<float4*>(y)[idx] =
-      reinterpret_cast<const float4*>(x + (size_t)img * L * c)[j];
+  reinterpret_cast<float4*>(y)[idx] = load4<TX>(x + (size_t)img * L * c, j);
 }
 
 // ---- im2col -----------------------------------------------------------------------------
@@ -239,36 +258,69 @@ __global__ __launch_bounds__(256) void crop_normalize_kernel(const uint8_t* __re
 
 }  // namespace
 
-hipError_t launch_layernorm(int dtype16, const float* x, long x_row_stride, const float* gamma,
-                            const float* beta, void* y, int rows, int c, hipStream_t s) {
+hipError_t launch_layernorm(int dtype16, const void* x, int x_dtype, long x_row_stride,
+                            const float* gamma, const float* beta, void* y, int rows, int c,
+                            hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
-  const int blocks = (rows + 3) / 4;
-  if (dtype16 == DT_F16)
-    hipLaunchKernelGGL(layernorm_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, x, x_row_stride,
-                       gamma, beta, reinterpret_cast<f16_t*>(y), rows, c);
-  else if (dtype16 == DT_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, x_row_stride,
-                       gamma, beta, reinterpret_cast<bf16_t*>(y), rows, c);
+  if (x_dtype != DT_F32 && x_dtype != dtype16) return hipErrorInvalidValue;
+  const dim3 g((rows + 3) / 4), b(256);
+  const bool x32 = x_dtype == DT_F32;
+  if (dtype16 == DT_F16) {
+    f16_t* yy = reinterpret_cast<f16_t*>(y);
+    if (x32)
+      hipLaunchKernelGGL((layernorm_kernel<f16_t, float>), g, b, 0, s,
+                         reinterpret_cast<const float*>(x), x_row_stride, gamma, beta, yy, rows, c);
+    else
+      hipLaunchKernelGGL((layernorm_kernel<f16_t, f16_t>), g, b, 0, s,
+                         reinterpret_cast<const f16_t*>(x), x_row_stride, gamma, beta, yy, rows, c);
+  } else if (dtype16 == DT_BF16) {
+    bf16_t* yy = reinterpret_cast<bf16_t*>(y);
+    if (x32)
+      hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), g, b, 0, s,
+                         reinterpret_cast<const float*>(x), x_row_stride, gamma, beta, yy, rows, c);
+    else
+      hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), g, b, 0, s,
+                         reinterpret_cast<const bf16_t*>(x), x_row_stride, gamma, beta, yy, rows, c);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_embed_ln_pre(void* x, int x_dtype, const float* cls, const float* pos,
+                               const float* gamma, const float* beta, int n, int L, int c,
+                               hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
+  const int rows = n * L;
+  const dim3 g((rows + 3) / 4), b(256);
+  if (x_dtype == DT_F32)
+    hipLaunchKernelGGL(embed_ln_pre_kernel<float>, g, b, 0, s, reinterpret_cast<float*>(x), cls, pos,
+                       gamma, beta, rows, L, c);
+  else if (x_dtype == DT_F16)
+    hipLaunchKernelGGL(embed_ln_pre_kernel<f16_t>, g, b, 0, s, reinterpret_cast<f16_t*>(x), cls, pos,
+                       gamma, beta, rows, L, c);
+  else if (x_dtype == DT_BF16)
+    hipLaunchKernelGGL(embed_ln_pre_kernel<bf16_t>, g, b, 0, s, reinterpret_cast<bf16_t*>(x), cls,
+                       pos, gamma, beta, rows, L, c);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-hipError_t launch_embed_ln_pre(float* x, const float* cls, const float* pos, const float* gamma,
-                               const float* beta, int n, int L, int c, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
-  const int rows = n * L;
-  hipLaunchKernelGGL(embed_ln_pre_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, cls, pos, gamma,
-                     beta, rows, L, c);
-  return hipGetLastError();
-}
-
-hipError_t launch_copy_cls(const float* x, float* y, int n, int L, int c, hipStream_t s) {
+hipError_t launch_copy_cls(const void* x, int x_dtype, float* y, int n, int L, int c, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   const long total = (long)n * (c >> 2);
-  hipLaunchKernelGGL(copy_cls_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, y, n, L, c);
+  const dim3 g((total + 255) / 256), b(256);
+  if (x_dtype == DT_F32)
+    hipLaunchKernelGGL(copy_cls_kernel<float>, g, b, 0, s, reinterpret_cast<const float*>(x), y, n, L, c);
+  else if (x_dtype == DT_F16)
+    hipLaunchKernelGGL(copy_cls_kernel<f16_t>, g, b, 0, s, reinterpret_cast<const f16_t*>(x), y, n, L, c);
+  else if (x_dtype == DT_BF16)
+    hipLaunchKernelGGL(copy_cls_kernel<bf16_t>, g, b, 0, s, reinterpret_cast<const bf16_t*>(x), y, n, L, c);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

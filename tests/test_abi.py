@@ -36,6 +36,7 @@ def test_abi_version_and_default_config(lib):
     assert (cfg.image_size, cfg.patch_size, cfg.stride, cfg.padding) == (224, 32, 32, 0)
     assert (cfg.width, cfg.layers, cfg.heads, cfg.mlp_dim, cfg.embed_dim) == (768, 12, 12, 3072, 512)
     assert cfg.compute_dtype == _lib.OAKE_F16 and cfg.max_batch == 256
+    assert cfg.residual_dtype == _lib.OAKE_F16
     assert C.sizeof(_lib.OakeConfig) == 48
 
 

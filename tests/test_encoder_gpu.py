@@ -22,11 +22,13 @@ def _check(out, ref, rtol, atol, cos_min=0.999):
     torch.testing.assert_close(out, ref, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize('dtype,rtol,atol', [(torch.float16, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 5e-3)])
+@pytest.mark.parametrize('resid32', [False, True])
+@pytest.mark.parametrize('dtype,rtol,atol', [(torch.float16, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 8e-3)])
 @pytest.mark.parametrize('n', [1, 5, 27])
-def test_encode_image_tiny(cuda, dtype, rtol, atol, n):
+def test_encode_image_tiny(cuda, dtype, rtol, atol, n, resid32):
     sd = synthetic_state_dict(**TINY)
-    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=16)
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=16,
+                         residual_dtype=torch.float32 if resid32 else None)
     x = synthetic_images(n, seed=n)
     ref = l2_normalize(encode_image_ref(sd, ViTConfig(**TINY), x))
     out = model.encode_image(x.to(cuda), normalize=True, out_dtype=torch.float32)
@@ -37,10 +39,12 @@ def test_encode_image_tiny(cuda, dtype, rtol, atol, n):
     _check(torch.nn.functional.normalize(raw.float()), ref, 3 * rtol, 3 * atol)
 
 
-def test_encode_image_vit_b32(cuda):
-    """Full ViT-B/32 (SURVEY.md §3.4 constants), 12 layers, 87.8 M parameters."""
+@pytest.mark.parametrize('resid32', [False, True])
+def test_encode_image_vit_b32(cuda, resid32):
+    """Full ViT-B/32 (SURVEY.md §3.4 constants), 12 layers, 87.8 M parameters; fp16 residual stream
+    (default, like the reference's fp16 GPU model) and fp32 residual stream."""
     sd = synthetic_state_dict()
-    model, _ = clip.load(sd, max_batch=8)
+    model, _ = clip.load(sd, max_batch=8, residual_dtype=torch.float32 if resid32 else None)
     x = synthetic_images(11, seed=3)  # 11 > max_batch: exercises the multi-pass path
     ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
     out = model.encode_image(x.to(cuda), normalize=True, out_dtype=torch.float16)
@@ -63,8 +67,9 @@ def test_encode_image_batch_invariance(cuda):
     assert torch.equal(full[[0, 17, 32]], one)
 
 
-def _objects_model(sd, arch, dtype=torch.float16, max_batch=8):
-    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=max_batch)
+def _objects_model(sd, arch, dtype=torch.float16, max_batch=8, resid32=False):
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=max_batch,
+                         residual_dtype=torch.float32 if resid32 else None)
     v = model.visual
     # the reference's surgery, oadp/oake/objects.py:292-301
     v.positional_embedding = v.interpolate_positional_embedding((v.grid * 2,) * 2)
@@ -92,9 +97,10 @@ def test_encode_objects_tiny(cuda, n):
     _check(out, ref, 1e-3, 1e-3)
 
 
-def test_encode_objects_vit_b32(cuda):
+@pytest.mark.parametrize('resid32', [False, True])
+def test_encode_objects_vit_b32(cuda, resid32):
     sd = synthetic_state_dict()
-    model, sd2, cfg = _objects_model(sd, {}, max_batch=4)
+    model, sd2, cfg = _objects_model(sd, {}, max_batch=4, resid32=resid32)
     x = synthetic_images(5, seed=77)
     g = torch.Generator().manual_seed(5)
     masks = (torch.rand(5, 1, 14, 14, generator=g) > 0.5).float()

@@ -81,17 +81,20 @@ def _gemm_case(lib, cuda, dtype, m, n, k):
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('rows,c', [(1, 768), (50, 768), (12800, 768), (7, 128), (33, 1024)])
-def test_layernorm(lib, cuda, dtype, rows, c):
+@pytest.mark.parametrize('x16', [False, True])
+def test_layernorm(lib, cuda, dtype, rows, c, x16):
     g = torch.Generator(device='cpu').manual_seed(rows + c)
     x = (torch.randn(rows, c, generator=g) * 3 + 0.7).to(cuda)
+    if x16:
+        x = x.to(dtype)
     gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(cuda)
     beta = (0.1 * torch.randn(c, generator=g)).to(cuda)
     y = torch.zeros(rows, c, dtype=dtype, device=cuda)
-    rc = lib.oake_debug_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                  rows, c, DT[dtype], _stream())
+    rc = lib.oake_debug_layernorm(x.data_ptr(), DT[dtype] if x16 else _lib.OAKE_F32, gamma.data_ptr(),
+                                  beta.data_ptr(), y.data_ptr(), rows, c, DT[dtype], _stream())
     assert rc == 0
     torch.cuda.synchronize()
-    ref = torch.nn.functional.layer_norm(x, (c,), gamma, beta, 1e-5)
+    ref = torch.nn.functional.layer_norm(x.float(), (c,), gamma, beta, 1e-5)
     tol = 2e-3 if dtype == torch.float16 else 2e-2
     torch.testing.assert_close(y.float(), ref, rtol=tol, atol=tol)
 

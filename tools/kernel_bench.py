@@ -25,7 +25,7 @@ for v in (0, 1, 2, 3):
 lib.oake_debug_set_attention_variant(3)
 x = torch.randn(n * L, 768, device=dev); g = torch.ones(768, device=dev); b = torch.zeros(768, device=dev)
 y = torch.empty(n * L, 768, device=dev, dtype=torch.float16)
-us = timeit(lambda: lib.oake_debug_layernorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), n * L, 768, 1, s))
+us = timeit(lambda: lib.oake_debug_layernorm(x.data_ptr(), 0, g.data_ptr(), b.data_ptr(), y.data_ptr(), n * L, 768, 1, s))
 print(f'layernorm: {us:.1f} us  ({(x.numel()*4+y.numel()*2)/us/1e6:.2f} TB/s)')
 # cold variants: flush caches between launches with a big memset
 junk = torch.empty(512 * 1024 * 1024, device=dev, dtype=torch.uint8)
@@ -37,4 +37,4 @@ def cold(fn):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); tot += e0.elapsed_time(e1)
     return tot / 5 * 1e3
 print(f'attention cold: {cold(lambda: lib.oake_debug_attention(qkv.data_ptr(), out.data_ptr(), n, L, H, 1, s)):.1f} us')
-print(f'layernorm cold: {cold(lambda: lib.oake_debug_layernorm(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), n * L, 768, 1, s)):.1f} us')
+print(f'layernorm cold: {cold(lambda: lib.oake_debug_layernorm(x.data_ptr(), 0, g.data_ptr(), b.data_ptr(), y.data_ptr(), n * L, 768, 1, s)):.1f} us')
