@@ -128,6 +128,14 @@ def main() -> None:
             'avg_launch_us': round(dom['total_ms'] * 1e3 / dom['launches'], 2),
             'traffic': None,
         }
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes over this same command
+        # (tools/pmc_traffic.py -> profiles/hbm_traffic.json); PMC cannot be sampled from in here.
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tpath) and args.batch == 256 and args.dtype == 'f16':
+            rec = json.load(open(tpath)).get(dom['name'])
+            if rec:
+                roofline['traffic'] = rec['hbm_bytes_per_launch']
+                roofline['traffic_unit'] = 'bytes/launch (PMC, profiles/hbm_traffic.json)'
         tot_ms = sum(p['total_ms'] for p in prof)
         kernels = {p['name']: {'ms_per_step': round(p['total_ms'] / 3, 4),
                                'share': round(p['total_ms'] / tot_ms, 4),

@@ -220,6 +220,9 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
 OAKE_API int oake_debug_set_attention_variant(int variant);
 /* GEMM configuration: -1 = automatic per shape, 0..4 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
+/* GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside), n < 0 = M slabs of
+ * -n tiles (column-major inside). */
+OAKE_API int oake_debug_set_gemm_panel(int panel);
 /* Debug: device buffer of 4608 uint64 receiving per-tile cycle stamps of the production GEMM
  * (entry, tile start, epilogue start, epilogue end; then per-block wall-clock entry/exit), or NULL. */
 OAKE_API int oake_debug_set_gemm_trace(void* d_trace);

@@ -3,13 +3,15 @@ is missing or fails to load, importing a model raises — the product path never
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 
 OAKE_OK = 0
 OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
 ABI_VERSION = 1
 
-LIB_PATH = pathlib.Path(__file__).resolve().parent / 'liboake_hip.so'
+# OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library
+LIB_PATH = pathlib.Path(os.environ.get('OAKE_LIB') or pathlib.Path(__file__).resolve().parent / 'liboake_hip.so')
 
 
 class OakeConfig(C.Structure):
@@ -52,6 +54,7 @@ SIGNATURES = {
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
     'oake_debug_set_attention_variant': (_I, [_I]),
     'oake_debug_set_gemm_variant': (_I, [_I]),
+    'oake_debug_set_gemm_panel': (_I, [_I]),
     'oake_debug_set_gemm_trace': (_I, [_VP]),
 }
 

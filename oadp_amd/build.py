@@ -9,6 +9,7 @@ from __future__ import annotations
 import hashlib
 import os
 import pathlib
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -23,7 +24,10 @@ ARCH = 'gfx950'
 FLAGS = [
     f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
     '-Wall', '-Wno-unused-function',
-]
+] + os.environ.get('OAKE_EXTRA_FLAGS', '').split()
+if os.environ.get('OAKE_LIB_OUT'):  # kernel experiments: build a differently-flagged copy beside the real one
+    LIB = pathlib.Path(os.environ['OAKE_LIB_OUT'])
+    BUILD = BUILD.parent / ('_build_' + LIB.stem)
 
 
 def _hipcc() -> str:
@@ -62,7 +66,8 @@ def _compile(src: str, force: bool) -> pathlib.Path:
             n = int(line.split('ScratchSize [bytes/lane]:')[1].split()[0])
             if n:
                 raise RuntimeError(f'{src}: kernel {name} spills {n} bytes/lane to scratch')
-    other = [l for l in r.stderr.splitlines() if 'remark:' not in l and l.strip()]
+    other = [l for l in r.stderr.splitlines()
+             if 'remark:' not in l and l.strip() and not re.match(r'\s*\d*\s*\|', l)]
     if other:
         sys.stderr.write('\n'.join(other) + '\n')
     stamp.write_text(dig)

@@ -26,6 +26,7 @@ namespace oake {
 extern int g_attention_use_tr;
 extern int g_attention_q32;
 extern int g_gemm_variant;
+extern int g_gemm_panel;
 extern unsigned long long* g_gemm_trace;
 }
 
@@ -819,6 +820,11 @@ int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
 
 int oake_debug_set_gemm_variant(int variant) {
   oake::g_gemm_variant = variant < 0 ? -1 : variant;
+  return OAKE_OK;
+}
+
+int oake_debug_set_gemm_panel(int panel) {
+  oake::g_gemm_panel = panel;
   return OAKE_OK;
 }
 

@@ -36,6 +36,7 @@
 
 namespace oake {
 
+int g_gemm_panel = 0;     // debug: 0 = default tile order, n > 0: N panels of n tiles, n < 0: M slabs of -n tiles
 int g_gemm_variant = -1;  // -1 = auto (per-shape), else forced configuration (tests / A-B runs)
 // debug: per-tile s_memtime stamps of gemm_pp_kernel's compute wave 0 / 4 (tools/gemm_trace.py)
 unsigned long long* g_gemm_trace = nullptr;
@@ -56,6 +57,7 @@ struct EpiParams {
 
 struct TileMap {
   int tiles_m, tiles_n, pn, nwg;
+  int by_m;  // 0: panels of pn tile-columns, row-major inside;  1: slabs of pn tile-rows, column-major inside
   unsigned long long* trace;  // [block < 64][group 2][tile < 8][4] cycle stamps, or nullptr
 };
 
@@ -81,11 +83,14 @@ __device__ __forceinline__ int sigma_col(int l) {
   return 32 * (ni >> 1) + 8 * (rho >> 2) + 4 * (ni & 1) + (rho & 3);
 }
 
-// logical tile t (panel-major order) -> tile origin
+// logical tile t -> tile origin.  The "outer" dimension (N for by_m = 0, M for by_m = 1) is cut into
+// panels of pn tiles; inside a panel the outer index runs fastest.
 __device__ __forceinline__ void tile_origin(const TileMap& tmap, int t, int BM, int BN, int& m0,
                                             int& n0) {
-  const int full = tmap.tiles_n / tmap.pn;
-  const int per_panel = tmap.tiles_m * tmap.pn;
+  const int outer = tmap.by_m ? tmap.tiles_m : tmap.tiles_n;
+  const int inner = tmap.by_m ? tmap.tiles_n : tmap.tiles_m;
+  const int full = outer / tmap.pn;
+  const int per_panel = inner * tmap.pn;
   int panel, pw, rem;
   if (t < full * per_panel) {
     panel = t / per_panel;
@@ -94,11 +99,12 @@ __device__ __forceinline__ void tile_origin(const TileMap& tmap, int t, int BM, 
   } else {
     panel = full;
     rem = t - full * per_panel;
-    pw = tmap.tiles_n - full * tmap.pn;
+    pw = outer - full * tmap.pn;
   }
-  const int tm = rem / pw;
-  m0 = tm * BM;
-  n0 = (panel * tmap.pn + (rem - tm * pw)) * BN;
+  const int ti = rem / pw;
+  const int to = panel * tmap.pn + (rem - ti * pw);
+  m0 = (tmap.by_m ? to : ti) * BM;
+  n0 = (tmap.by_m ? ti : to) * BN;
 }
 
 // Per-lane source pointer of DMA piece `ii` (stage rows [8 ii, 8 ii + 8)): lane -> (row 8 ii +
@@ -594,19 +600,42 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     OAKE_BAR();
     OAKE_MFMA_BLOCK();
     OAKE_BAR();
+#ifndef OAKE_EXP
+#define OAKE_EXP 0
+#endif
+#define OAKE_TRICKLE_ONE()                                                  \
+  do {                                                                      \
+    if constexpr (TRICKLE) if (pend_next < NPEND) {                         \
+      OAKE_PIN();                                                           \
+      _Pragma("unroll") for (int i = 0; i < NPEND; ++i)                     \
+          if (i == pend_next) OAKE_STORE_PEND(i);                           \
+      ++pend_next;                                                          \
+      OAKE_PIN();                                                           \
+    }                                                                       \
+  } while (0)
+#if OAKE_EXP == 3
+    OAKE_TRICKLE_ONE();
+#endif
     OAKE_LOAD_FRAGS(c_buf, koff1);
     OAKE_LGKM0();
-    if constexpr (TRICKLE) if (pend_next < NPEND) {
-      // one trickled store per K-tile, in this wave's load phase (static register indices: a
-      // runtime-indexed register array would live in scratch)
-      OAKE_PIN();
-#pragma unroll
-      for (int i = 0; i < NPEND; ++i)
-        if (i == pend_next) OAKE_STORE_PEND(i);
-      ++pend_next;
-    }
+#if OAKE_EXP == 0
+    OAKE_TRICKLE_ONE();
+#elif OAKE_EXP == 2
+    if constexpr (TRICKLE) if (pend_next < NPEND) ++pend_next;
+#endif
     OAKE_BAR();
+#if OAKE_EXP == 1
+    {
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)
+          acc[0][ni] = T16<T>::mfma(bf[ni], af[0], acc[0][ni]);
+      OAKE_TRICKLE_ONE();
+      _Pragma("unroll") for (int mi = 1; mi < MI; ++mi)
+          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+    }
+#else
     OAKE_MFMA_BLOCK();
+#endif
     c_buf = c_buf == NSTAGE - 1 ? 0 : c_buf + 1;
     if (++c_kt == nk) {
       // tile done
@@ -678,7 +707,14 @@ TileMap make_tilemap(const GemmArgs& a, int BM, int BN) {
   tmap.nwg = tmap.tiles_m * tmap.tiles_n;
   int pn = 768 / BN;  // ~768-column panels: a W panel of K=768 is ~1.2 MB of an XCD's 4 MiB L2
   pn = pn < 1 ? 1 : pn;
-  tmap.pn = pn > tmap.tiles_n ? tmap.tiles_n : pn;
+  tmap.by_m = 0;
+  if (g_gemm_panel > 0) pn = g_gemm_panel;
+  if (g_gemm_panel < 0) {
+    tmap.by_m = 1;
+    pn = -g_gemm_panel;
+  }
+  const int outer = tmap.by_m ? tmap.tiles_m : tmap.tiles_n;
+  tmap.pn = pn > outer ? outer : pn;
   tmap.trace = g_gemm_trace;
   return tmap;
 }
