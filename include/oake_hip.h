@@ -206,6 +206,12 @@ OAKE_API int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bi
 /* C16[m,n] = (quick_gelu?)(A * W^T + bias) stored in the 16-bit operand type (n % 8 == 0). */
 OAKE_API int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, void* d_c,
                       int m, int n, int k, int dtype16, int gelu, void* stream);
+/* C16[m,n] = (quick_gelu?)(LayerNorm(x)[m,k] * W^T + bias) with the LayerNorm folded into the GEMM
+ * (gamma into W, beta into bias, per-row statistics applied in the epilogue); x is 16-bit [m,k],
+ * W fp32 [n,k].  Synchronous (allocates temporaries). */
+OAKE_API int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gamma,
+                         const float* d_beta, const float* d_bias, void* d_c, int m, int n, int k,
+                         int dtype16, int gelu, void* stream);
 /* y = LayerNorm(x) over last dim `c` (eps 1e-5), x [rows,c] of x_dtype (OAKE_F32 or dtype16)
  * -> y 16-bit [rows,c]. */
 OAKE_API int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, const float* d_beta,

@@ -49,6 +49,7 @@ SIGNATURES = {
     'oake_profile_reset': (_I, [_VP]),
     'oake_debug_gemm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_gemm16': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    'oake_debug_ln_gemm16': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     'oake_debug_layernorm': (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),
     'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),

@@ -40,6 +40,12 @@ struct LayerW {
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
   void *in_w = nullptr, *out_w = nullptr, *fc_w = nullptr, *proj_w = nullptr;  // 16-bit [N,K]
   float *in_b = nullptr, *out_b = nullptr, *fc_b = nullptr, *proj_b = nullptr;
+  // LayerNorm folded into the consuming GEMM (16-bit residual stream; rowops.hip fold_ln_kernel):
+  // fp32 masters of the two weights that follow a LayerNorm, their gamma-scaled 16-bit copies, the
+  // column sums of those and the beta-shifted biases
+  float *in_w32 = nullptr, *fc_w32 = nullptr;
+  void *in_wf = nullptr, *fc_wf = nullptr;
+  float *in_cs = nullptr, *fc_cs = nullptr, *in_bf = nullptr, *fc_bf = nullptr;
 };
 
 struct ProfSlot {
@@ -72,6 +78,7 @@ struct oake_handle {
   void* proj = nullptr;       // [embed, width] 16-bit (visual.proj transposed: GEMM W operand)
   std::vector<LayerW> layers;
   std::map<std::string, bool> loaded;
+  bool folded = false;        // LayerW::*_wf / *_cs / *_bf are current
   float* stage = nullptr;     // fp32 staging for uploads
   size_t stage_elems = 0;
 
@@ -80,6 +87,7 @@ struct oake_handle {
   void* x = nullptr;          // residual stream [B*L, C] of type xdt
   void *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr;
   float* y = nullptr;
+  float* rowstat = nullptr;   // [B*L, 2] LayerNorm (rstd, -mean*rstd) of the residual rows
   float* e32 = nullptr;       // [B, embed] fp32 head projection
   void *yn = nullptr, *qkv_y = nullptr, *att_y = nullptr, *h_y = nullptr;
 
@@ -240,12 +248,14 @@ void oake_destroy(oake_handle* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
-                  h->yn, h->qkv_y, h->att_y, h->h_y, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp};
+                  h->yn, h->qkv_y, h->att_y, h->h_y, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
+                  h->rowstat};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& l : h->layers) {
     void* lp[] = {l.ln1_g, l.ln1_b, l.ln2_g, l.ln2_b, l.in_w, l.out_w, l.fc_w, l.proj_w,
-                  l.in_b, l.out_b, l.fc_b, l.proj_b};
+                  l.in_b, l.out_b, l.fc_b, l.proj_b, l.in_w32, l.fc_w32, l.in_wf, l.fc_wf,
+                  l.in_cs, l.fc_cs, l.in_bf, l.fc_bf};
     for (void* p : lp)
       if (p) (void)hipFree(p);
   }
@@ -323,6 +333,16 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
     A((void**)&l.out_b, C * 4);
     A((void**)&l.fc_b, F * 4);
     A((void**)&l.proj_b, C * 4);
+    if (h->xdt != DT_F32) {
+      A((void**)&l.in_w32, 3 * C * C * 4);
+      A((void**)&l.fc_w32, F * C * 4);
+      A(&l.in_wf, 3 * C * C * e16());
+      A(&l.fc_wf, F * C * e16());
+      A((void**)&l.in_cs, 3 * C * 4);
+      A((void**)&l.fc_cs, F * 4);
+      A((void**)&l.in_bf, 3 * C * 4);
+      A((void**)&l.fc_bf, F * 4);
+    }
   }
   h->stage_elems = std::max<size_t>(std::max<size_t>(C * h->kpatch, F * C), std::max<size_t>(3 * C * C, L * C));
   A((void**)&h->stage, h->stage_elems * 4);
@@ -334,6 +354,7 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   A(&h->att, B * L * C * e16());
   A(&h->hbuf, B * L * F * e16());
   A((void**)&h->y, B * C * 4);
+  A((void**)&h->rowstat, (B * L + 2) * 2 * 4);
   A((void**)&h->e32, B * E * 4);
   A(&h->yn, B * C * e16());
   A(&h->qkv_y, B * 3 * C * e16());
@@ -415,6 +436,7 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
       HIP_TRY(h, hipMemcpy(h->stage, data, numel * 4, hipMemcpyHostToDevice));
       HIP_TRY(h, launch_scale_f32(h->stage, C * C, 0.125f, 0));
       HIP_TRY(h, launch_cast_f32_to_16(h->dt16, h->stage, w.in_w, numel, 1.0f, 0));
+      if (w.in_w32) HIP_TRY(h, hipMemcpyAsync(w.in_w32, h->stage, numel * 4, hipMemcpyDeviceToDevice, 0));
       HIP_TRY(h, hipStreamSynchronize(0));
     } else if (leaf == "attn.in_proj_bias") {
       F32(w.in_b, 3 * C);
@@ -422,7 +444,10 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
       HIP_TRY(h, hipStreamSynchronize(0));
     } else if (leaf == "attn.out_proj.weight") W16(w.out_w, C * C);
     else if (leaf == "attn.out_proj.bias") F32(w.out_b, C);
-    else if (leaf == "mlp.c_fc.weight") W16(w.fc_w, F * C);
+    else if (leaf == "mlp.c_fc.weight") {
+      W16(w.fc_w, F * C);
+      if (w.fc_w32) HIP_TRY(h, hipMemcpy(w.fc_w32, data, numel * 4, hipMemcpyHostToDevice));
+    }
     else if (leaf == "mlp.c_fc.bias") F32(w.fc_b, F);
     else if (leaf == "mlp.c_proj.weight") W16(w.proj_w, C * F);
     else if (leaf == "mlp.c_proj.bias") F32(w.proj_b, C);
@@ -431,6 +456,7 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
 #undef F32
 #undef W16
   it->second = true;
+  h->folded = false;
   return OAKE_OK;
 }
 
@@ -440,9 +466,11 @@ namespace {
 
 // ---- shared pieces of the two schedules -------------------------------------------------------
 int gemm(oake_handle* h, hipStream_t s, const char* name, int epi, const void* A, const void* W,
-         const float* bias, void* out, int M, int N, int K, int ldo) {
+         const float* bias, void* out, int M, int N, int K, int ldo,
+         const float* rowstat = nullptr, const float* colsum = nullptr) {
   GemmArgs a{};
   a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
+  a.rowstat = rowstat; a.colsum = colsum;
   RUN(h, s, name, 2.0 * M * N * K, 0.0, launch_gemm(h->dt16, epi, a, s));
   return OAKE_OK;
 }
@@ -465,6 +493,26 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   return OAKE_OK;
 }
 
+// ln_1 + in-proj of the main token stream -> h->qkv ([T, 3C]; kv_only: columns C.. only)
+int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_only) {
+  const int C = h->cfg.width;
+  const int n0 = kv_only ? C : 0, N = 3 * C - n0;
+  const size_t es = 2;
+  const char* name = kv_only ? "gemm_kv" : "gemm_qkv";
+  char* out = reinterpret_cast<char*>(h->qkv) + (size_t)n0 * es;
+  if (h->xdt == DT_F32) {
+    RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
+        launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
+    const char* wp = reinterpret_cast<const char*>(w.in_w) + (size_t)n0 * C * es;
+    return gemm(h, s, name, EPI_T16_BIAS, h->xn, wp, w.in_b + n0, out, T, N, C, 3 * C);
+  }
+  // 16-bit residual stream: ln_1 folded into the GEMM, which reads the raw residual rows
+  RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
+  const char* wp = reinterpret_cast<const char*>(w.in_wf) + (size_t)n0 * C * es;
+  return gemm(h, s, name, EPI_T16_BIAS_LN, h->x, wp, w.in_bf + n0, out, T, N, C, 3 * C, h->rowstat,
+              w.in_cs + n0);
+}
+
 int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   // attention + out_proj + MLP of the main token stream (qkv already computed)
   const int C = h->cfg.width, F = h->cfg.mlp_dim, L = h->tokens, T = nb * L;
@@ -473,9 +521,17 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
       launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, s));
   int rc;
   if ((rc = gemm(h, s, "gemm_out_proj", h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16, h->att, w.out_w, w.out_b, h->x, T, C, C, C))) return rc;
-  RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-      launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln2_g, w.ln2_b, h->xn, T, C, s));
-  if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU, h->xn, w.fc_w, w.fc_b, h->hbuf, T, F, C, F))) return rc;
+  if (h->xdt == DT_F32) {
+    RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
+        launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln2_g, w.ln2_b, h->xn, T, C, s));
+    if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU, h->xn, w.fc_w, w.fc_b, h->hbuf, T, F, C, F))) return rc;
+  } else {
+    // ln_2 folded into c_fc: the GEMM reads the raw residual rows
+    RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
+    if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU_LN, h->x, w.fc_wf, w.fc_bf, h->hbuf, T, F, C, F,
+                   h->rowstat, w.fc_cs)))
+      return rc;
+  }
   if ((rc = gemm(h, s, "gemm_c_proj", h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16, h->hbuf, w.proj_w, w.proj_b, h->x, T, C, F, C))) return rc;
   return OAKE_OK;
 }
@@ -497,6 +553,18 @@ int head(oake_handle* h, hipStream_t s, const void* x, int x_dtype, long row_str
 int check_ready(oake_handle* h) {
   const int m = oake_missing_tensors(h);
   if (m != 0) return fail(h, OAKE_ERR_STATE, std::to_string(m) + " weight tensors not loaded");
+  if (!h->folded && h->xdt != DT_F32) {
+    const int C = h->cfg.width, F = h->cfg.mlp_dim;
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (auto& w : h->layers) {
+      HIP_TRY(h, launch_fold_ln(h->dt16, w.in_w32, w.ln1_g, w.ln1_b, w.in_b, w.in_wf, w.in_cs, w.in_bf,
+                                3 * C, C, 0));
+      HIP_TRY(h, launch_fold_ln(h->dt16, w.fc_w32, w.ln2_g, w.ln2_b, w.fc_b, w.fc_wf, w.fc_cs, w.fc_bf,
+                                F, C, 0));
+    }
+    HIP_TRY(h, hipStreamSynchronize(0));
+  }
+  h->folded = true;
   return OAKE_OK;
 }
 
@@ -591,10 +659,7 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
     if ((rc = patch_embed(h, s, imgs, in_dtype, nb))) return rc;
     for (int l = 0; l < c.layers; ++l) {
       const LayerW& w = h->layers[l];
-      RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-          launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
-      if ((rc = gemm(h, s, "gemm_qkv", EPI_T16_BIAS, h->xn, w.in_w, w.in_b, h->qkv, T, 3 * C, C, 3 * C)))
-        return rc;
+      if ((rc = main_in_proj(h, s, w, T, false))) return rc;
       if ((rc = main_block_tail(h, s, w, nb))) return rc;
     }
     if ((rc = head(h, s, h->x, h->xdt, (long)L * C, outp, out_dtype, normalize, nb))) return rc;
@@ -638,18 +703,8 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       const LayerW& w = h->layers[l];
       const bool last = (l == c.layers - 1);
       // ln_1 + in-proj of the main stream: k/v of patch rows serve both streams (Appendix C #1)
-      RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-          launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
-      if (!last) {
-        if ((rc = gemm(h, s, "gemm_qkv", EPI_T16_BIAS, h->xn, w.in_w, w.in_b, h->qkv, T, 3 * C, C, 3 * C)))
-          return rc;
-      } else {
-        // last layer: the main stream's q is dead (Appendix C #2) — project k and v only
-        const char* wkv = reinterpret_cast<const char*>(w.in_w) + (size_t)C * C * 2;
-        char* okv = reinterpret_cast<char*>(h->qkv) + (size_t)C * 2;
-        if ((rc = gemm(h, s, "gemm_kv", EPI_T16_BIAS, h->xn, wkv, w.in_b + C, okv, T, 2 * C, C, 3 * C)))
-          return rc;
-      }
+      // (last layer: the main stream's q is dead (Appendix C #2) — k and v only)
+      if ((rc = main_in_proj(h, s, w, T, last))) return rc;
       // object-token stream (Hooks.residual_attention_block_forward_pre, objects.py:223-247)
       RUN(h, s, "layernorm_y", 0.0, (double)nb * C * 6,
           launch_layernorm(h->dt16, h->y, DT_F32, C, w.ln1_g, w.ln1_b, h->yn, nb, C, s));
@@ -800,6 +855,29 @@ int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, voi
   a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
   return dbg(launch_gemm(dtype16, gelu ? EPI_T16_GELU : EPI_T16_BIAS, a,
                          reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gamma,
+                         const float* d_beta, const float* d_bias, void* d_c, int m, int n, int k,
+                         int dtype16, int gelu, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  void* wf = nullptr;
+  float *cs = nullptr, *bf = nullptr, *stat = nullptr;
+  hipError_t e = hipMalloc(&wf, (size_t)n * k * 2);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&cs), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bf), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&stat), ((size_t)m + 2) * 8);
+  if (e == hipSuccess) e = launch_fold_ln(dtype16, d_w32, d_gamma, d_beta, d_bias, wf, cs, bf, n, k, s);
+  if (e == hipSuccess) e = launch_rowstat(d_x, dtype16, k, stat, m, k, s);
+  if (e == hipSuccess) {
+    GemmArgs a{};
+    a.A = d_x; a.W = wf; a.bias = bf; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
+    a.rowstat = stat; a.colsum = cs;
+    e = launch_gemm(dtype16, gelu ? EPI_T16_GELU_LN : EPI_T16_BIAS_LN, a, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(wf); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(stat);
+  return dbg(e);
 }
 
 int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, const float* d_beta,

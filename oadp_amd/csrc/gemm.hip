@@ -53,6 +53,8 @@ struct EpiParams {
   const float* pos;
   int P2;
   int L;
+  const float2* rowstat;  // EPI_*_LN: per-row (rstd, -mean * rstd)
+  const float* colsum;    // EPI_*_LN: per-column sum of the (gamma-folded) weights
 };
 
 struct TileMap {
@@ -67,11 +69,18 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 template <int EPI>
 struct EpiTraits {
   // 16-bit outputs use the paired column mapping (see header comment)
-  static constexpr bool kPaired = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU ||
-                                   EPI == EPI_RESID16 || EPI == EPI_PATCH16);
+  static constexpr bool kLn = (EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN);
+  static constexpr bool kGelu = (EPI == EPI_T16_GELU || EPI == EPI_T16_GELU_LN);
   // pure stores (no read-modify-write): the persistent kernel may hold them back and trickle them
-  static constexpr bool kTrickle = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU);
+  static constexpr bool kTrickle = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || kLn);
+  static constexpr bool kPaired = (kTrickle || EPI == EPI_RESID16 || EPI == EPI_PATCH16);
 };
+
+// acc -> acc + bias, or the folded LayerNorm  rstd * acc + (-mean rstd) * colsum + bias
+template <bool LN>
+__device__ __forceinline__ float epi_affine(float acc, float bias, float cs, float2 rs) {
+  return LN ? fmaf(acc, rs.x, fmaf(rs.y, cs, bias)) : acc + bias;
+}
 
 // Column (relative to the wave's TN-column block) held by LDS row l = 16*ni + rho of that block.
 // identity: l.   paired: tiles (2t, 2t+1) interleave 4-column groups so lane-group g of the MFMA
@@ -130,26 +139,61 @@ __device__ __forceinline__ const char* piece_src(const T* A, const T* W, int M, 
 // of the wave's block (n0 + wn*TN), g = lane>>4.  All bias / residual / pos-emb loads of a row are
 // issued before its first store so the wave waits once per row; interior tiles take a branch-free
 // path (with per-store exec-mask branches hipcc put an s_waitcnt vmcnt(0) in front of every store).
-template <typename T, int EPI, int MI, int NI, bool FULL>
+//
+// ELDS (persistent kernel): bias / colsum / rowstat of the tile were staged into LDS by the DMA waves
+// (EpiLds layout below) — `elds` points at that block, lcol / lrow are the lane's first column / row
+// relative to the tile.  Otherwise they are read from global memory.
+struct EpiLds {
+  static constexpr int kBias = 0;        // float[BN <= 256]
+  static constexpr int kColsum = 1024;   // float[BN <= 256]
+  static constexpr int kRowstat = 2048;  // float2[BM <= 160]
+  static constexpr int kBytes = 2048 + 160 * 8;
+};
+
+template <bool ELDS>
+__device__ __forceinline__ float4 epi_vec4(const float* gptr, int n, const char* elds, int off, int lc) {
+  if constexpr (ELDS)
+    return *reinterpret_cast<const float4*>(elds + off + lc * 4);
+  else
+    return *reinterpret_cast<const float4*>(gptr + n);
+}
+
+template <typename T, int EPI, int MI, int NI, bool FULL, bool ELDS>
 __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mbase, int nwave, int g,
-                                                   int M, int N, const EpiParams& ep, bool reset) {
+                                                   int M, int N, const EpiParams& ep, bool reset,
+                                                   const char* elds, int lcol, int lrow) {
   constexpr bool PAIRED = EpiTraits<EPI>::kPaired;
   if (PAIRED) {
     static_assert(!PAIRED || NI % 2 == 0, "paired mapping needs an even number of column tiles");
     constexpr int NP = NI / 2;
     typedef typename T16<T>::vec8 vec8;
-    float4 b0[NP], b1[NP];
+    constexpr bool LN = EpiTraits<EPI>::kLn;
+    float4 b0[NP], b1[NP], c0[LN ? NP : 1], c1[LN ? NP : 1];
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       const int n = nwave + 32 * t + 8 * g;
       const bool ok = EPI != EPI_PATCH16 && ep.bias != nullptr && (FULL || n < N);
-      b0[t] = ok ? *reinterpret_cast<const float4*>(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      b1[t] = ok ? *reinterpret_cast<const float4*>(ep.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int lc = lcol + 32 * t + 8 * g;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      b0[t] = ok ? epi_vec4<ELDS>(ep.bias, n, elds, EpiLds::kBias, lc) : z4;
+      b1[t] = ok ? epi_vec4<ELDS>(ep.bias, n + 4, elds, EpiLds::kBias, lc + 4) : z4;
+      if constexpr (LN) {
+        const bool okc = FULL || n < N;
+        c0[t] = okc ? epi_vec4<ELDS>(ep.colsum, n, elds, EpiLds::kColsum, lc) : z4;
+        c1[t] = okc ? epi_vec4<ELDS>(ep.colsum, n + 4, elds, EpiLds::kColsum, lc + 4) : z4;
+      }
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = mbase + mi * 16;
       const bool mok = FULL || m < M;
+      float2 rs = make_float2(1.f, 0.f);
+      if constexpr (LN) {
+        if constexpr (ELDS)
+          rs = *reinterpret_cast<const float2*>(elds + EpiLds::kRowstat + (lrow + mi * 16) * 8);
+        else if (mok)
+          rs = ep.rowstat[m];
+      }
       size_t orow = (size_t)m;
       const float* posrow = nullptr;
       if (EPI == EPI_PATCH16) {
@@ -182,9 +226,14 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
           acc[mi][2 * t + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (!FULL && !(mok && n < N)) continue;
-        lo[0] += b0[t].x; lo[1] += b0[t].y; lo[2] += b0[t].z; lo[3] += b0[t].w;
-        hi[0] += b1[t].x; hi[1] += b1[t].y; hi[2] += b1[t].z; hi[3] += b1[t].w;
-        if (EPI == EPI_T16_GELU) {
+        {
+          const float4 cl = c0[LN ? t : 0], ch = c1[LN ? t : 0];
+          lo[0] = epi_affine<LN>(lo[0], b0[t].x, cl.x, rs); lo[1] = epi_affine<LN>(lo[1], b0[t].y, cl.y, rs);
+          lo[2] = epi_affine<LN>(lo[2], b0[t].z, cl.z, rs); lo[3] = epi_affine<LN>(lo[3], b0[t].w, cl.w, rs);
+          hi[0] = epi_affine<LN>(hi[0], b1[t].x, ch.x, rs); hi[1] = epi_affine<LN>(hi[1], b1[t].y, ch.y, rs);
+          hi[2] = epi_affine<LN>(hi[2], b1[t].z, ch.z, rs); hi[3] = epi_affine<LN>(hi[3], b1[t].w, ch.w, rs);
+        }
+        if (EpiTraits<EPI>::kGelu) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             lo[r] = quick_gelu(lo[r]);
@@ -214,7 +263,7 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
   for (int ni = 0; ni < NI; ++ni) {
     const int n = nbase + ni * 16;
     bv[ni] = (EPI != EPI_PATCH && ep.bias != nullptr && (FULL || n < N))
-                 ? *reinterpret_cast<const float4*>(ep.bias + n)
+                 ? epi_vec4<ELDS>(ep.bias, n, elds, EpiLds::kBias, lcol + 4 * g + ni * 16)
                  : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
@@ -263,35 +312,41 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
 // issue); trickled, the same bytes ride under the next tile's MFMAs at ~2 TB/s.
 template <typename T, int EPI, int MI, int NI, int MI0>
 __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&pend)[MI - MI0][NI / 2],
-                                                 int nwave, int g, const EpiParams& ep, T* row0_ptr) {
+                                                 const EpiParams& ep, T* row0_ptr, const char* elds,
+                                                 int lcol, int lrow) {
   constexpr int NP = NI / 2;
-  float4 b0[NP], b1[NP];
+  constexpr bool LN = EpiTraits<EPI>::kLn;
+  // Epilogue constants come from LDS (staged by the DMA waves): no global-load latency here, and no
+  // VMEM results pending at the K-loop header (hipcc would guard the loop-top ds_reads with
+  // s_waitcnt vmcnt(0) on every iteration, which then waits for the previous trickled store).
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
-    const int n = nwave + 32 * t + 8 * g;
+    const int lc = lcol + 32 * t;
     const bool ok = ep.bias != nullptr;
-    b0[t] = ok ? *reinterpret_cast<const float4*>(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    b1[t] = ok ? *reinterpret_cast<const float4*>(ep.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  // Retire the bias loads HERE, explicitly: left to hipcc, their result registers are "pending" at the
-  // K-loop header (they get reused as ds_read destinations) and it guards the loop-top reads with
-  // s_waitcnt vmcnt(0) on EVERY iteration — which then waits for the previous trickled store to
-  // complete (+600 cycles per K-tile).
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b0 = ok ? epi_vec4<true>(nullptr, 0, elds, EpiLds::kBias, lc) : z4;
+    const float4 b1 = ok ? epi_vec4<true>(nullptr, 0, elds, EpiLds::kBias, lc + 4) : z4;
+    const float4 cl = LN ? epi_vec4<true>(nullptr, 0, elds, EpiLds::kColsum, lc) : z4;
+    const float4 ch = LN ? epi_vec4<true>(nullptr, 0, elds, EpiLds::kColsum, lc + 4) : z4;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int t = 0; t < NP; ++t) {
+    for (int mi = 0; mi < MI; ++mi) {
       f32x4 lo = acc[mi][2 * t], hi = acc[mi][2 * t + 1];
-      acc[mi][2 * t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[mi][2 * t + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      lo[0] += b0[t].x; lo[1] += b0[t].y; lo[2] += b0[t].z; lo[3] += b0[t].w;
-      hi[0] += b1[t].x; hi[1] += b1[t].y; hi[2] += b1[t].z; hi[3] += b1[t].w;
-      if (EPI == EPI_T16_GELU) {
+      float2 r = make_float2(1.f, 0.f);
+      if constexpr (LN) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(3))) f32x2* lds_f2_t;
+        const f32x2 rv = *(lds_f2_t)(elds + EpiLds::kRowstat + (lrow + mi * 16) * 8);
+        r = make_float2(rv[0], rv[1]);
+      }
+      lo[0] = epi_affine<LN>(lo[0], b0.x, cl.x, r); lo[1] = epi_affine<LN>(lo[1], b0.y, cl.y, r);
+      lo[2] = epi_affine<LN>(lo[2], b0.z, cl.z, r); lo[3] = epi_affine<LN>(lo[3], b0.w, cl.w, r);
+      hi[0] = epi_affine<LN>(hi[0], b1.x, ch.x, r); hi[1] = epi_affine<LN>(hi[1], b1.y, ch.y, r);
+      hi[2] = epi_affine<LN>(hi[2], b1.z, ch.z, r); hi[3] = epi_affine<LN>(hi[3], b1.w, ch.w, r);
+      if (EpiTraits<EPI>::kGelu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          lo[r] = quick_gelu(lo[r]);
-          hi[r] = quick_gelu(hi[r]);
+        for (int r4 = 0; r4 < 4; ++r4) {
+          lo[r4] = quick_gelu(lo[r4]);
+          hi[r4] = quick_gelu(hi[r4]);
         }
       }
       const uint2 p0 = pack4<T>(lo[0], lo[1], lo[2], lo[3]);
@@ -310,9 +365,19 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], int mbase, i
                                               int M, int N, const EpiParams& ep, bool reset,
                                               bool interior) {
   if (interior)
-    tile_epilogue_impl<T, EPI, MI, NI, true>(acc, mbase, nwave, g, M, N, ep, reset);
+    tile_epilogue_impl<T, EPI, MI, NI, true, false>(acc, mbase, nwave, g, M, N, ep, reset, nullptr, 0, 0);
   else
-    tile_epilogue_impl<T, EPI, MI, NI, false>(acc, mbase, nwave, g, M, N, ep, reset);
+    tile_epilogue_impl<T, EPI, MI, NI, false, false>(acc, mbase, nwave, g, M, N, ep, reset, nullptr, 0, 0);
+}
+
+template <typename T, int EPI, int MI, int NI>
+__device__ __forceinline__ void tile_epilogue_lds(f32x4 (&acc)[MI][NI], int mbase, int nwave, int g,
+                                                  int M, int N, const EpiParams& ep, bool reset,
+                                                  bool interior, const char* elds, int lcol, int lrow) {
+  if (interior)
+    tile_epilogue_impl<T, EPI, MI, NI, true, true>(acc, mbase, nwave, g, M, N, ep, reset, elds, lcol, lrow);
+  else
+    tile_epilogue_impl<T, EPI, MI, NI, false, true>(acc, mbase, nwave, g, M, N, ep, reset, elds, lcol, lrow);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -492,6 +557,38 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     };
     // producer cursor: flat K-tile s_g (k position s_kt of tile s_tile) goes to ring slot s_buf
     int s_g = 0, s_kt = 0, s_tile = 0, s_buf = 0;
+    // consumer position (compute group 0): K-tile d_kt of tile d_tile.  In the last phase of a tile's
+    // FIRST K-tile (group 1 finished the previous tile's epilogue one phase earlier) one DMA wave
+    // each stages the tile's bias / colsum / rowstat block into the EpiLds area; it is covered by
+    // the next iteration's vmcnt wait + barrier, long before the tile's epilogue (nk >= 3).
+    int d_kt = 0, d_tile = 0;
+#define OAKE_STAGE_EPI()                                                                        \
+  do {                                                                                          \
+    if (d_kt == 0) {                                                                            \
+      int _m0, _n0;                                                                             \
+      tile_origin(tmap, xb + xslot + d_tile * per_xcd, BM, BN, _m0, _n0);                       \
+      char* _e = smem + NSTAGE * kStageBytes;                                                   \
+      int _n = _n0 + 4 * lane;                                                                  \
+      _n = _n + 4 <= N ? _n : N - 4;                                                            \
+      if (lw == 0 && ep.bias != nullptr && EPI != EPI_PATCH && EPI != EPI_PATCH16)             \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.bias + _n),                             \
+                                         (lds_ptr_t)(_e + EpiLds::kBias), 16, 0, 0);            \
+      if (EpiTraits<EPI>::kLn && lw == 1)                                                       \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.colsum + _n),                           \
+                                         (lds_ptr_t)(_e + EpiLds::kColsum), 16, 0, 0);          \
+      if (EpiTraits<EPI>::kLn && lw >= 2 && (lw == 2 || lane < (BM - 128) / 2)) {               \
+        int _m = _m0 + (lw - 2) * 128 + 2 * lane;                                               \
+        _m = _m < M ? _m : 0; /* pairs (m, m+1): the buffer holds M + 1 rows */                 \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.rowstat + _m),                          \
+                                         (lds_ptr_t)(_e + EpiLds::kRowstat + (lw - 2) * 1024),  \
+                                         16, 0, 0);                                             \
+      }                                                                                         \
+    }                                                                                           \
+    if (++d_kt == nk) {                                                                         \
+      d_kt = 0;                                                                                 \
+      ++d_tile;                                                                                 \
+    }                                                                                           \
+  } while (0)
 #define OAKE_STAGE(j0_, j1_)                                                                 \
   do {                                                                                       \
     if (s_g < total) {                                                                       \
@@ -532,6 +629,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       OAKE_STAGE(Q2, Q3);
       OAKE_BAR();
       OAKE_STAGE(Q3, NPL);
+      OAKE_STAGE_EPI();
       const bool newer = g + 2 < total;
       OAKE_ADVANCE();
       if (newer) OAKE_VMCNT(NPL); else OAKE_VMCNT(0);  // flat K-tile g+1 landed
@@ -539,6 +637,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     }
     OAKE_BAR();  // pairs with compute group 1's last phase
 #undef OAKE_STAGE
+#undef OAKE_STAGE_EPI
 #undef OAKE_ADVANCE
 #undef OAKE_VMCNT
     return;
@@ -554,6 +653,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   const int b_base = kATileBytes + (wn * TN + frow) * kRowBytes;
   const int koff0 = ((0 * 4 + fg) ^ fsw) << 4;
   const int koff1 = ((1 * 4 + fg) ^ fsw) << 4;
+  const char* elds = smem + NSTAGE * kStageBytes;
+  // (cycle stamps are compiled out of the LN-folded variants: they sit exactly at the VGPR limit)
+  unsigned long long* const trace = EpiTraits<EPI>::kLn ? nullptr : tmap.trace;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -575,10 +677,19 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                   \
             acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);                        \
   } while (0)
+  // (after the epilogue, not while it consumes the rows: zeroed early, the accumulators would stay
+  // live — as zeros — next to the packed tile and the epilogue constants)
+#define OAKE_ZERO_ACC()                                                                     \
+  do {                                                                                      \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                       \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                   \
+            acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};                                        \
+  } while (0)
 #define OAKE_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
   // pending (packed, not yet stored) 16-bit tile: see tile_pack_paired
-  constexpr int MI0 = 1;  // rows stored immediately at tile end (register budget, see tile_pack_paired)
+  constexpr int MI0 = 1;  // rows stored immediately at tile end: the K-loop holds acc + fragments +
+                          // (MI - MI0) * NI/2 * 4 pending registers inside 168 VGPRs (3 waves per SIMD)
   constexpr bool TRICKLE = EpiTraits<EPI>::kTrickle;
   constexpr int NPEND = TRICKLE ? (MI - MI0) * (NI / 2) : 1;
   uint4 pend[TRICKLE ? MI - MI0 : 1][TRICKLE ? NI / 2 : 1];
@@ -588,54 +699,31 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   *reinterpret_cast<uint4*>(pend_ptr + (size_t)((i_) / (NI / 2) + MI0) * 16 * ep.ldo +       \
                             ((i_) % (NI / 2)) * 32) = pend[(i_) / (NI / 2)][(i_) % (NI / 2)]
 
-  const unsigned long long t_entry = tmap.trace ? __builtin_readcyclecounter() : 0;
-  if (tmap.trace != nullptr && tid == 0) tmap.trace[4096 + blockIdx.x * 2] = wall_clock64();
+  const unsigned long long t_entry = trace ? __builtin_readcyclecounter() : 0;
+  if (trace != nullptr && tid == 0) trace[4096 + blockIdx.x * 2] = wall_clock64();
   OAKE_BAR();            // b0
   if (late) OAKE_BAR();  // group 1 runs one phase behind group 0 (and the DMA waves)
   int c_buf = 0, c_kt = 0, c_tile = 0;
-  unsigned long long t_tile = tmap.trace ? __builtin_readcyclecounter() : 0;
+  unsigned long long t_tile = trace ? __builtin_readcyclecounter() : 0;
   for (int g = 0; g < total; ++g) {
     OAKE_LOAD_FRAGS(c_buf, koff0);
     OAKE_LGKM0();
     OAKE_BAR();
     OAKE_MFMA_BLOCK();
     OAKE_BAR();
-#ifndef OAKE_EXP
-#define OAKE_EXP 0
-#endif
-#define OAKE_TRICKLE_ONE()                                                  \
-  do {                                                                      \
-    if constexpr (TRICKLE) if (pend_next < NPEND) {                         \
-      OAKE_PIN();                                                           \
-      _Pragma("unroll") for (int i = 0; i < NPEND; ++i)                     \
-          if (i == pend_next) OAKE_STORE_PEND(i);                           \
-      ++pend_next;                                                          \
-      OAKE_PIN();                                                           \
-    }                                                                       \
-  } while (0)
-#if OAKE_EXP == 3
-    OAKE_TRICKLE_ONE();
-#endif
     OAKE_LOAD_FRAGS(c_buf, koff1);
     OAKE_LGKM0();
-#if OAKE_EXP == 0
-    OAKE_TRICKLE_ONE();
-#elif OAKE_EXP == 2
-    if constexpr (TRICKLE) if (pend_next < NPEND) ++pend_next;
-#endif
-    OAKE_BAR();
-#if OAKE_EXP == 1
-    {
-      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)
-          acc[0][ni] = T16<T>::mfma(bf[ni], af[0], acc[0][ni]);
-      OAKE_TRICKLE_ONE();
-      _Pragma("unroll") for (int mi = 1; mi < MI; ++mi)
-          _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+    if constexpr (TRICKLE) if (pend_next < NPEND) {
+      // one trickled store per K-tile, in this wave's load phase (static register indices: a
+      // runtime-indexed register array would live in scratch)
+      OAKE_PIN();
+#pragma unroll
+      for (int i = 0; i < NPEND; ++i)
+        if (i == pend_next) OAKE_STORE_PEND(i);
+      ++pend_next;
     }
-#else
+    OAKE_BAR();
     OAKE_MFMA_BLOCK();
-#endif
     c_buf = c_buf == NSTAGE - 1 ? 0 : c_buf + 1;
     if (++c_kt == nk) {
       // tile done
@@ -643,54 +731,71 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       int m0, n0;
       tile_origin(tmap, xb + xslot + c_tile * per_xcd, BM, BN, m0, n0);
       ++c_tile;
-      const bool interior = m0 + BM <= M && n0 + BN <= N;
-      OAKE_PIN();
-      const unsigned long long t_ep = tmap.trace ? __builtin_readcyclecounter() : 0;
-      if constexpr (TRICKLE) {
-        // flush what is still pending from the previous tile (only when a tile has < NPEND K-tiles)
-#pragma unroll
-        for (int i = 0; i < NPEND; ++i)
-          if (i >= pend_next) OAKE_STORE_PEND(i);
-        pend_next = NPEND;
-      }
-      bool deferred = false;
-      if constexpr (TRICKLE) {
-        if (interior && c_tile < my_tiles) {
-          pend_ptr = reinterpret_cast<T*>(ep.out) + (size_t)(m0 + wm * TM + frow) * ep.ldo + n0 +
-                     wn * TN + 8 * fg;
-          tile_pack_paired<T, EPI, MI, NI, MI0>(acc, pend, n0 + wn * TN, fg, ep, pend_ptr);
-          pend_next = 0;
-          deferred = true;
-        }
-      }
-      if (!deferred && c_tile < my_tiles) {
-        // edge tile or fp32 output with more tiles to come: store now
-        tile_epilogue<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, true,
-                                      interior);
-      }
       // (the block's LAST tile is stored after the loop: done here, group 0's stores would sit in
       // front of a barrier and group 1 would start its own epilogue only once they are issued)
-      if (tmap.trace != nullptr && (tid & 255) == 0 && blockIdx.x < 64 && c_tile <= 8) {
+      if (c_tile < my_tiles) {
+        const bool interior = m0 + BM <= M && n0 + BN <= N;
         OAKE_PIN();
-        unsigned long long* tr =
-            tmap.trace + (((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 + (c_tile - 1)) * 4;
-        tr[0] = t_entry; tr[1] = t_tile; tr[2] = t_ep; tr[3] = __builtin_readcyclecounter();
-        t_tile = tr[3];
+        // re-derive the lane coordinates behind an opaque asm: hipcc would otherwise hoist every
+        // epilogue address out of the K-loop and keep it in a VGPR across it
+        int etid = tid;
+        asm volatile("" : "+v"(etid));
+        const int frow = etid & 15, fg = (etid & 63) >> 4;
+        const unsigned long long t_ep = trace ? __builtin_readcyclecounter() : 0;
+        bool deferred = false;
+        if constexpr (TRICKLE) {
+          // flush what is still pending from the previous tile (only when a tile has < NPEND K-tiles)
+#pragma unroll
+          for (int i = 0; i < NPEND; ++i)
+            if (i >= pend_next) OAKE_STORE_PEND(i);
+          pend_next = NPEND;
+          if (interior) {
+            pend_ptr = reinterpret_cast<T*>(ep.out) + (size_t)(m0 + wm * TM + frow) * ep.ldo + n0 +
+                       wn * TN + 8 * fg;
+            tile_pack_paired<T, EPI, MI, NI, MI0>(acc, pend, ep, pend_ptr, elds, wn * TN + 8 * fg,
+                                                  wm * TM + frow);
+            pend_next = 0;
+            deferred = true;
+          }
+        }
+        if (!deferred)  // edge tile, fp32 output or read-modify-write epilogue: store now
+          tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep,
+                                            false, interior, elds, wn * TN, wm * TM + frow);
+        OAKE_ZERO_ACC();
+        if (trace != nullptr && (tid & 255) == 0 && blockIdx.x < 64 && c_tile <= 8) {
+          OAKE_PIN();
+          unsigned long long* tr =
+              trace + (((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 + (c_tile - 1)) * 4;
+          tr[0] = t_entry; tr[1] = t_tile; tr[2] = t_ep; tr[3] = __builtin_readcyclecounter();
+          t_tile = tr[3];
+        }
       }
     }
     OAKE_BAR();
   }
   if (!late) OAKE_BAR();
+  if constexpr (TRICKLE) {
+#pragma unroll
+    for (int i = 0; i < NPEND; ++i)
+      if (i >= pend_next) OAKE_STORE_PEND(i);
+  }
   {
     int m0, n0;
     tile_origin(tmap, xb + xslot + (my_tiles - 1) * per_xcd, BM, BN, m0, n0);
-    tile_epilogue<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, false,
-                                  m0 + BM <= M && n0 + BN <= N);
+    const unsigned long long t_ep = trace ? __builtin_readcyclecounter() : 0;
+    tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, false,
+                                      m0 + BM <= M && n0 + BN <= N, elds, wn * TN, wm * TM + frow);
+    if (trace != nullptr && (tid & 255) == 0 && blockIdx.x < 64 && my_tiles <= 8) {
+      unsigned long long* tr =
+          trace + (((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 + (my_tiles - 1)) * 4;
+      tr[0] = t_entry; tr[1] = t_tile; tr[2] = t_ep; tr[3] = __builtin_readcyclecounter();
+    }
   }
-  if (tmap.trace != nullptr && tid == 256) {
+  if (trace != nullptr && tid == 256) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    tmap.trace[4096 + blockIdx.x * 2 + 1] = wall_clock64();
+    trace[4096 + blockIdx.x * 2 + 1] = wall_clock64();
   }
+#undef OAKE_ZERO_ACC
 #undef OAKE_STORE_PEND
 #undef OAKE_LOAD_FRAGS
 #undef OAKE_MFMA_BLOCK
@@ -731,7 +836,8 @@ hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const TileMap tmap = make_tilemap(a, BM, BN);
-  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L};
+  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum};
   hipLaunchKernelGGL(kern, dim3(tmap.nwg), dim3(WM * WN * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
@@ -740,7 +846,8 @@ hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
 
 template <typename T, int EPI, int BM, int BN, int WM, int WN>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
-  constexpr int lds = 3 * (BM + BN) * kRowBytes;
+  constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
+  static_assert(BM <= 160 && BN <= 256, "EpiLds layout");
   static bool attr_set = false;
   static int num_cu = 0;
   auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN>;
@@ -755,12 +862,15 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
     num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
+  if (a.K < 3 * BK)  // the EpiLds staging needs >= 3 K-tiles per tile
+    return launch_simple<T, EPI, BM, BN, WM, WN>(a, s);
   const TileMap tmap = make_tilemap(a, BM, BN);
   int grid = (num_cu / 8) * 8;  // one persistent block per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
   const int need = ((tmap.nwg + 7) / 8) * 8;
   if (grid > need) grid = need;
-  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L};
+  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum};
   hipLaunchKernelGGL(kern, dim3(grid), dim3((WM * WN + 4) * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
@@ -802,6 +912,8 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_PATCH: return launch_variant<T, EPI_PATCH>(v, a, s);
     case EPI_RESID16: return launch_variant<T, EPI_RESID16>(v, a, s);
     case EPI_PATCH16: return launch_variant<T, EPI_PATCH16>(v, a, s);
+    case EPI_T16_BIAS_LN: return launch_variant<T, EPI_T16_BIAS_LN>(v, a, s);
+    case EPI_T16_GELU_LN: return launch_variant<T, EPI_T16_GELU_LN>(v, a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -811,8 +923,12 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
   if (a.K % BK != 0 || a.N % 4 != 0 || a.ldo % 4 != 0) return hipErrorInvalidValue;
-  if ((epi == EPI_T16_BIAS || epi == EPI_T16_GELU || epi == EPI_RESID16 || epi == EPI_PATCH16) &&
+  if ((epi == EPI_T16_BIAS || epi == EPI_T16_GELU || epi == EPI_RESID16 || epi == EPI_PATCH16 ||
+       epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) &&
       (a.N % 8 != 0 || a.ldo % 8 != 0))
+    return hipErrorInvalidValue;
+  if ((epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) &&
+      (a.rowstat == nullptr || a.colsum == nullptr || a.bias == nullptr))
     return hipErrorInvalidValue;
   if (dtype16 == DT_F16) return launch_epi<f16_t>(epi, a, s);
   if (dtype16 == DT_BF16) return launch_epi<bf16_t>(epi, a, s);

@@ -16,7 +16,11 @@ enum GemmEpi {
   EPI_RESID = 3,      // out fp32 [M,ldo] += acc + bias                (attn out_proj, MLP c_proj)
   EPI_PATCH = 4,      // out fp32 x[(m/P2)*L + 1 + m%P2, :] = acc + pos[1 + m%P2, :]   (conv1)
   EPI_RESID16 = 5,    // EPI_RESID on a 16-bit residual stream (read-modify-write in T16)
-  EPI_PATCH16 = 6     // EPI_PATCH writing a 16-bit residual stream
+  EPI_PATCH16 = 6,    // EPI_PATCH writing a 16-bit residual stream
+  // LayerNorm folded in (rowops.hip, fold_ln_kernel): W carries gamma, `bias` is b + W beta, and
+  // out = rowstat[m].x * acc + rowstat[m].y * colsum[n] + bias[n]   (then QuickGELU for _GELU_LN)
+  EPI_T16_BIAS_LN = 7,
+  EPI_T16_GELU_LN = 8
 };
 
 struct GemmArgs {
@@ -30,6 +34,9 @@ struct GemmArgs {
   const float* pos;   // [L, N] positional embedding (fp32)
   int P2;             // patches per image
   int L;              // tokens per image (P2 + 1)
+  // EPI_*_LN only
+  const float* rowstat;  // [M + 1, 2] (rstd, -mean * rstd) of the raw A rows (launch_rowstat; row M is padding)
+  const float* colsum;   // [N] sum_k W[n,k]
 };
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
@@ -40,6 +47,14 @@ hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
 hipError_t launch_layernorm(int dtype16, const void* x, int x_dtype, long x_row_stride,
                             const float* gamma, const float* beta, void* y, int rows, int c,
                             hipStream_t s);
+
+// stat[row] = (rstd, -mean * rstd) of LayerNorm over x[row, :c]   (the EPI_*_LN GEMM epilogues)
+hipError_t launch_rowstat(const void* x, int x_dtype, long x_row_stride, float* stat, int rows, int c,
+                          hipStream_t s);
+// wf = 16-bit(w32 * gamma[k]) [n_out,k]; colsum[n] = sum_k wf[n,k]; bf[n] = bias[n] + sum_k w32[n,k] beta[k]
+hipError_t launch_fold_ln(int dtype16, const float* w32, const float* gamma, const float* beta,
+                          const float* bias, void* wf, float* colsum, float* bf, int n_out, int k,
+                          hipStream_t s);
 
 // x[n*L + t, :] (in place, fp32 or 16-bit): t == 0 -> cls + pos[0]; then ln_pre over every row.
 hipError_t launch_embed_ln_pre(void* x, int x_dtype, const float* cls, const float* pos,

@@ -80,6 +80,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x
     }
 }
 
+// ---- LayerNorm folded into the consuming GEMM (16-bit residual stream) -------------------------
+// LN(x) W^T + b  =  rstd * (x (g o W)^T)  -  rstd * mean * colsum  +  (b + W beta)      with
+// colsum[n] = sum_k (g o W)[n,k]: the GEMM runs on the RAW residual rows with gamma-scaled weights
+// and its epilogue applies the two per-row scalars below, so the normalised activations are never
+// written to / re-read from HBM (2 x 19.7 MB per LayerNorm at bs 256) — only these 8 B per row.
+// stat[row] = (rstd, -mean * rstd); statistics of the row exactly as the GEMM will read it.
+template <typename TX>
+__global__ __launch_bounds__(256) void rowstat_kernel(const TX* __restrict__ x, long stride,
+                                                      float2* __restrict__ stat, int rows, int c) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = c >> 2;
+  const TX* xr = x + (size_t)row * stride;
+  float4 v[kMaxVec];
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) v[i] = load4<TX>(xr, lane + 64 * i);
+  float mean, rstd;
+  ln_stats(v, lane, nv, c, mean, rstd);
+  if (lane == 0) stat[row] = make_float2(rstd, -mean * rstd);
+}
+
+// One wave per output feature n:  wf[n,:] = T(w32[n,:] * gamma),  colsum[n] = sum_k wf[n,k] (the
+// ROUNDED weights, i.e. what the MFMA multiplies the row mean's contribution by),
+// bf[n] = bias[n] + sum_k w32[n,k] * beta[k].
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ w32,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ bias,
+                                                      T* __restrict__ wf, float* __restrict__ colsum,
+                                                      float* __restrict__ bf, int n_out, int k) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= n_out) return;
+  const float* wr = w32 + (size_t)n * k;
+  T* fr = wf + (size_t)n * k;
+  float cs = 0.f, bb = 0.f;
+  for (int kk = lane; kk < k; kk += 64) {
+    const float w = wr[kk];
+    const T f = to16<T>(w * gamma[kk]);
+    fr[kk] = f;
+    cs += to32<T>(f);
+    bb += w * beta[kk];
+  }
+  cs = wave_sum(cs);
+  bb = wave_sum(bb);
+  if (lane == 0) {
+    colsum[n] = cs;
+    bf[n] = bias[n] + bb;
+  }
+}
+
 // x[n*L + t] in place: t == 0 takes cls + pos[0] (patch rows already carry conv + pos from the
 // EPI_PATCH GEMM epilogue), then ln_pre.
 template <typename TX>
@@ -285,6 +339,42 @@ hipError_t launch_layernorm(int dtype16, const void* x, int x_dtype, long x_row_
   } else {
     return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_rowstat(const void* x, int x_dtype, long x_row_stride, float* stat, int rows, int c,
+                          hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
+  const dim3 g((rows + 3) / 4), b(256);
+  float2* st = reinterpret_cast<float2*>(stat);
+  if (x_dtype == DT_F32)
+    hipLaunchKernelGGL((rowstat_kernel<float>), g, b, 0, s, reinterpret_cast<const float*>(x),
+                       x_row_stride, st, rows, c);
+  else if (x_dtype == DT_F16)
+    hipLaunchKernelGGL((rowstat_kernel<f16_t>), g, b, 0, s, reinterpret_cast<const f16_t*>(x),
+                       x_row_stride, st, rows, c);
+  else if (x_dtype == DT_BF16)
+    hipLaunchKernelGGL((rowstat_kernel<bf16_t>), g, b, 0, s, reinterpret_cast<const bf16_t*>(x),
+                       x_row_stride, st, rows, c);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_ln(int dtype16, const float* w32, const float* gamma, const float* beta,
+                          const float* bias, void* wf, float* colsum, float* bf, int n_out, int k,
+                          hipStream_t s) {
+  if (n_out <= 0) return hipSuccess;
+  const dim3 g((n_out + 3) / 4), b(256);
+  if (dtype16 == DT_F16)
+    hipLaunchKernelGGL((fold_ln_kernel<f16_t>), g, b, 0, s, w32, gamma, beta, bias,
+                       reinterpret_cast<f16_t*>(wf), colsum, bf, n_out, k);
+  else if (dtype16 == DT_BF16)
+    hipLaunchKernelGGL((fold_ln_kernel<bf16_t>), g, b, 0, s, w32, gamma, beta, bias,
+                       reinterpret_cast<bf16_t*>(wf), colsum, bf, n_out, k);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -65,6 +65,39 @@ def test_gemm_16bit_epilogues(lib, cuda, variant, gelu, dtype, m, n, k):
     torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize('variant', [0, 1, 4, 5])
+@pytest.mark.parametrize('gelu', [0, 1])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (50, 2304, 768), (333, 136, 512),
+                                   (12800, 1024, 256)])
+def test_gemm_layernorm_folded(lib, cuda, variant, gelu, dtype, m, n, k):
+    """LayerNorm folded into the consuming GEMM (16-bit residual stream): gamma in W, beta in the
+    bias, per-row (rstd, -mean*rstd) applied in the epilogue == GEMM(LayerNorm(x)) in fp32."""
+    g = torch.Generator(device='cpu').manual_seed(m + n + k + gelu)
+    x = torch.randn(m, k, generator=g) * 1.5 + 0.3
+    x[:, 5] *= 12.0          # CLIP's residual stream has a few large-magnitude channels
+    x[:, k // 2] += 7.0
+    x = x.to(dtype).to(cuda)
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(k, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(k, generator=g)).to(cuda)
+    bias = torch.randn(n, generator=g).to(cuda)
+    c = torch.full((m, n), float('nan'), dtype=dtype, device=cuda)
+    lib.oake_debug_set_gemm_variant(variant)
+    try:
+        rc = lib.oake_debug_ln_gemm16(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                      bias.data_ptr(), c.data_ptr(), m, n, k, DT[dtype], gelu, _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.oake_debug_set_gemm_variant(-1)
+    ref = torch.nn.functional.layer_norm(x.float(), (k,), gamma, beta, 1e-5) @ w.t() + bias
+    if gelu:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
+
+
 def _gemm_case(lib, cuda, dtype, m, n, k):
     g = torch.Generator(device='cpu').manual_seed(m * 7 + n * 3 + k)
     a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
