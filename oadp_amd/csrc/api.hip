@@ -88,6 +88,9 @@ struct oake_handle {
   void *xn = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr;
   float* y = nullptr;
   float* rowstat = nullptr;   // [B*L, 2] LayerNorm (rstd, -mean*rstd) of the residual rows
+  float* rowpart = nullptr;   // [B*L, 16, 2] (sum, sum^2) slices handed from GEMM to GEMM
+  bool stat_fused = false;    // this pass: statistics via rowpart (else the rowstat kernel)
+  int nparts = 0;             // valid slices per row in rowpart (1 after embed, width/64 after a GEMM)
   float* e32 = nullptr;       // [B, embed] fp32 head projection
   void *yn = nullptr, *qkv_y = nullptr, *att_y = nullptr, *h_y = nullptr;
 
@@ -249,7 +252,7 @@ void oake_destroy(oake_handle* h) {
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
                   h->yn, h->qkv_y, h->att_y, h->h_y, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
-                  h->rowstat};
+                  h->rowstat, h->rowpart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& l : h->layers) {
@@ -355,6 +358,7 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   A(&h->hbuf, B * L * F * e16());
   A((void**)&h->y, B * C * 4);
   A((void**)&h->rowstat, (B * L + 2) * 2 * 4);
+  A((void**)&h->rowpart, B * L * 32 * 4);
   A((void**)&h->e32, B * E * 4);
   A(&h->yn, B * C * e16());
   A(&h->qkv_y, B * 3 * C * e16());
@@ -471,7 +475,14 @@ int gemm(oake_handle* h, hipStream_t s, const char* name, int epi, const void* A
   GemmArgs a{};
   a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
   a.rowstat = rowstat; a.colsum = colsum;
+  // row statistics travel GEMM -> GEMM when the main stream's shapes run the persistent kernel
+  if (h->stat_fused && (epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN)) {
+    a.rowpart_in = h->rowpart;
+    a.nparts = h->nparts;
+  }
+  if (h->stat_fused && epi == EPI_RESID16 && out == h->x) a.rowpart_out = h->rowpart;
   RUN(h, s, name, 2.0 * M * N * K, 0.0, launch_gemm(h->dt16, epi, a, s));
+  if (a.rowpart_out) h->nparts = N / 64;
   return OAKE_OK;
 }
 
@@ -488,8 +499,16 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   a.M = nb * h->p2; a.N = C; a.K = h->kpatch; a.ldo = C; a.pos = h->pos; a.P2 = h->p2; a.L = L;
   RUN(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0,
       launch_gemm(h->dt16, h->xdt == DT_F32 ? EPI_PATCH : EPI_PATCH16, a, s));
+  // 16-bit residual stream + every main-stream GEMM on the persistent kernel: LayerNorm statistics
+  // are produced by the kernel that writes x (here: slot 0) and consumed by the next GEMM
+  const int T = nb * L;
+  h->stat_fused = h->xdt != DT_F32 && C % 64 == 0 && C / 64 <= 16 &&
+                  gemm_uses_persistent(T, C, C) && gemm_uses_persistent(T, C, c.mlp_dim) &&
+                  gemm_uses_persistent(T, 2 * C, C) && gemm_uses_persistent(T, c.mlp_dim, C);
   RUN(h, s, "embed_ln_pre", 0.0, 2.0 * nb * L * C * 4,
-      launch_embed_ln_pre(h->x, h->xdt, h->cls, h->pos, h->lnpre_g, h->lnpre_b, nb, L, C, s));
+      launch_embed_ln_pre(h->x, h->xdt, h->cls, h->pos, h->lnpre_g, h->lnpre_b, nb, L, C,
+                          h->stat_fused ? h->rowpart : nullptr, s));
+  h->nparts = 1;
   return OAKE_OK;
 }
 
@@ -507,7 +526,8 @@ int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_
     return gemm(h, s, name, EPI_T16_BIAS, h->xn, wp, w.in_b + n0, out, T, N, C, 3 * C);
   }
   // 16-bit residual stream: ln_1 folded into the GEMM, which reads the raw residual rows
-  RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
+  if (!h->stat_fused)
+    RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
   const char* wp = reinterpret_cast<const char*>(w.in_wf) + (size_t)n0 * C * es;
   return gemm(h, s, name, EPI_T16_BIAS_LN, h->x, wp, w.in_bf + n0, out, T, N, C, 3 * C, h->rowstat,
               w.in_cs + n0);
@@ -527,7 +547,8 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
     if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU, h->xn, w.fc_w, w.fc_b, h->hbuf, T, F, C, F))) return rc;
   } else {
     // ln_2 folded into c_fc: the GEMM reads the raw residual rows
-    RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
+    if (!h->stat_fused)
+      RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
     if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU_LN, h->x, w.fc_wf, w.fc_bf, h->hbuf, T, F, C, F,
                    h->rowstat, w.fc_cs)))
       return rc;
@@ -868,15 +889,18 @@ int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gam
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bf), (size_t)n * 4);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&stat), ((size_t)m + 2) * 8);
   if (e == hipSuccess) e = launch_fold_ln(dtype16, d_w32, d_gamma, d_beta, d_bias, wf, cs, bf, n, k, s);
+  float* part = nullptr;
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&part), (size_t)m * 32 * 4);
   if (e == hipSuccess) e = launch_rowstat(d_x, dtype16, k, stat, m, k, s);
+  if (e == hipSuccess) e = launch_rowsums(d_x, dtype16, k, part, m, k, s);
   if (e == hipSuccess) {
     GemmArgs a{};
     a.A = d_x; a.W = wf; a.bias = bf; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
-    a.rowstat = stat; a.colsum = cs;
+    a.rowstat = stat; a.colsum = cs; a.rowpart_in = part; a.nparts = 1;
     e = launch_gemm(dtype16, gelu ? EPI_T16_GELU_LN : EPI_T16_BIAS_LN, a, s);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(wf); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(stat);
+  (void)hipFree(wf); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(stat); (void)hipFree(part);
   return dbg(e);
 }
 

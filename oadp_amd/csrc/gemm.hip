@@ -53,9 +53,18 @@ struct EpiParams {
   const float* pos;
   int P2;
   int L;
-  const float2* rowstat;  // EPI_*_LN: per-row (rstd, -mean * rstd)
+  const float2* rowstat;  // EPI_*_LN, simple kernel: per-row (rstd, -mean * rstd) (launch_rowstat)
   const float* colsum;    // EPI_*_LN: per-column sum of the (gamma-folded) weights
+  // Row statistics carried between the persistent kernels instead of a separate pass over x:
+  // the residual epilogue (EPI_RESID16) leaves (sum x, sum x^2) of every 64-column slice of a row in
+  // rowpart_out[m][kRowParts] (slice = column / 64); the next LN-folded GEMM's DMA waves add up the
+  // first `nparts` slices of its rows (fixed order) and put (rstd, -mean rstd) into LDS.
+  float2* rowpart_out;
+  const float2* rowpart_in;
+  int nparts;
+  float inv_k;            // 1 / K
 };
+constexpr int kRowParts = 16;  // float2 slots per row (128 B): N <= 1024 residual width
 
 struct TileMap {
   int tiles_m, tiles_n, pn, nwg;
@@ -203,6 +212,7 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
         posrow = ep.pos + (size_t)(1 + p) * N;
       }
       T* orow_ptr = reinterpret_cast<T*>(ep.out) + orow * ep.ldo;
+      float ps1 = 0.f, ps2 = 0.f;  // this lane's share of the row's (sum x, sum x^2)
       // this row's residual (8 x 16-bit) / pos-emb (8 x fp32) loads first, then the stores
       vec8 xr[NP];
       float4 p0[NP], p1[NP];
@@ -249,9 +259,26 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
           lo[0] += p0[t].x; lo[1] += p0[t].y; lo[2] += p0[t].z; lo[3] += p0[t].w;
           hi[0] += p1[t].x; hi[1] += p1[t].y; hi[2] += p1[t].z; hi[3] += p1[t].w;
         }
+        if constexpr (ELDS && EPI == EPI_RESID16) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ps1 += lo[r] + hi[r];
+            ps2 = fmaf(lo[r], lo[r], fmaf(hi[r], hi[r], ps2));
+          }
+        }
         const uint2 q0 = pack4<T>(lo[0], lo[1], lo[2], lo[3]);
         const uint2 q1 = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
         *reinterpret_cast<uint4*>(orow_ptr + n) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+      }
+      if constexpr (ELDS && EPI == EPI_RESID16) {
+        if (ep.rowpart_out != nullptr) {  // (uniform) the wave's 64-column slice of row m
+          static_assert(NI * 16 == 64, "row-statistics slices are 64 columns wide");
+          ps1 += __shfl_xor(ps1, 16, 64);
+          ps2 += __shfl_xor(ps2, 16, 64);
+          ps1 += __shfl_xor(ps1, 32, 64);
+          ps2 += __shfl_xor(ps2, 32, 64);
+          if (g == 0 && mok) ep.rowpart_out[(size_t)m * kRowParts + nwave / 64] = make_float2(ps1, ps2);
+        }
       }
     }
     return;
@@ -559,7 +586,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     int s_g = 0, s_kt = 0, s_tile = 0, s_buf = 0;
     // consumer position (compute group 0): K-tile d_kt of tile d_tile.  In the last phase of a tile's
     // FIRST K-tile (group 1 finished the previous tile's epilogue one phase earlier) one DMA wave
-    // each stages the tile's bias / colsum / rowstat block into the EpiLds area; it is covered by
+    // each stages the tile's bias / colsum block into the EpiLds area; it is covered by
     // the next iteration's vmcnt wait + barrier, long before the tile's epilogue (nk >= 3).
     int d_kt = 0, d_tile = 0;
 #define OAKE_STAGE_EPI()                                                                        \
@@ -576,13 +603,6 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       if (EpiTraits<EPI>::kLn && lw == 1)                                                       \
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.colsum + _n),                           \
                                          (lds_ptr_t)(_e + EpiLds::kColsum), 16, 0, 0);          \
-      if (EpiTraits<EPI>::kLn && lw >= 2 && (lw == 2 || lane < (BM - 128) / 2)) {               \
-        int _m = _m0 + (lw - 2) * 128 + 2 * lane;                                               \
-        _m = _m < M ? _m : 0; /* pairs (m, m+1): the buffer holds M + 1 rows */                 \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.rowstat + _m),                          \
-                                         (lds_ptr_t)(_e + EpiLds::kRowstat + (lw - 2) * 1024),  \
-                                         16, 0, 0);                                             \
-      }                                                                                         \
     }                                                                                           \
     if (++d_kt == nk) {                                                                         \
       d_kt = 0;                                                                                 \
@@ -621,9 +641,55 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     OAKE_ADVANCE();
     if (total >= 2) OAKE_VMCNT(NPL); else OAKE_VMCNT(0);
     OAKE_BAR();  // b0: flat K-tile 0 published
+    // LN-folded epilogues: DMA wave lw owns rows [lw * BM/4, +BM/4) of the tile, one row per lane.  At
+    // the tile's first K-tile it loads the row's partial (sum x, sum x^2) slices, adds them up in
+    // slot order and — one barrier later, when group 1 is done with the previous tile's epilogue —
+    // writes (rstd, -mean rstd) into EpiLds::kRowstat, 11 K-tiles ahead of the epilogue that reads it.
+    // (hipcc guards the loaded values with s_waitcnt vmcnt(0): once per tile this wave also waits
+    // for its newest pieces.)
+    constexpr bool LN = EpiTraits<EPI>::kLn;
+    constexpr int RPW = BM / NL;  // rows per DMA wave
+    static_assert(RPW <= 64, "one row per lane");
+    float st_rstd = 0.f, st_shift = 0.f;
     for (int g = 0; g < total; ++g) {
+      if constexpr (LN) {
+        if (d_kt == 0 && lane < RPW) {
+          int _m0, _n0;
+          tile_origin(tmap, xb + xslot + d_tile * per_xcd, BM, BN, _m0, _n0);
+          int _m = _m0 + lw * RPW + lane;
+          _m = _m < M ? _m : M - 1;
+          // all slices in flight at once (two per 16-B load), then summed in slot order
+          const float4* _p = reinterpret_cast<const float4*>(ep.rowpart_in + (size_t)_m * kRowParts);
+          float4 _v[kRowParts / 2];
+#pragma unroll
+          for (int i = 0; i < kRowParts / 2; ++i)
+            _v[i] = 2 * i < ep.nparts ? _p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          float _s1 = 0.f, _s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < kRowParts / 2; ++i) {
+            _s1 += _v[i].x;
+            _s2 += _v[i].y;
+            if (2 * i + 1 < ep.nparts) {
+              _s1 += _v[i].z;
+              _s2 += _v[i].w;
+            }
+          }
+          const float _mean = _s1 * ep.inv_k;
+          const float _var = fmaxf(_s2 * ep.inv_k - _mean * _mean, 0.f);
+          st_rstd = rsqrtf(_var + 1e-5f);
+          st_shift = -_mean * st_rstd;
+        }
+      }
       OAKE_STAGE(0, Q1);  // flat K-tile g+2, a quarter of the pieces per phase
       OAKE_BAR();
+      if constexpr (LN) {
+        if (d_kt == 0 && lane < RPW) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef __attribute__((address_space(3))) f32x2* lds_f2w_t;
+          *(lds_f2w_t)(smem + NSTAGE * kStageBytes + EpiLds::kRowstat + (lw * RPW + lane) * 8) =
+              f32x2{st_rstd, st_shift};
+        }
+      }
       OAKE_STAGE(Q1, Q2);
       OAKE_BAR();
       OAKE_STAGE(Q2, Q3);
@@ -837,7 +903,9 @@ hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
   }
   const TileMap tmap = make_tilemap(a, BM, BN);
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
-               reinterpret_cast<const float2*>(a.rowstat), a.colsum};
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum,
+               reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
+               a.nparts, 1.0f / (float)a.K};
   hipLaunchKernelGGL(kern, dim3(tmap.nwg), dim3(WM * WN * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
@@ -870,7 +938,9 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   const int need = ((tmap.nwg + 7) / 8) * 8;
   if (grid > need) grid = need;
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
-               reinterpret_cast<const float2*>(a.rowstat), a.colsum};
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum,
+               reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
+               a.nparts, 1.0f / (float)a.K};
   hipLaunchKernelGGL(kern, dim3(grid), dim3((WM * WN + 4) * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
@@ -920,6 +990,12 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+bool gemm_uses_persistent(int M, int N, int K) {
+  GemmArgs a{};
+  a.M = M; a.N = N; a.K = K;
+  return pick_variant(a) == 4 && K >= 3 * BK;
+}
+
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
   if (a.K % BK != 0 || a.N % 4 != 0 || a.ldo % 4 != 0) return hipErrorInvalidValue;
@@ -927,9 +1003,13 @@ hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {
        epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) &&
       (a.N % 8 != 0 || a.ldo % 8 != 0))
     return hipErrorInvalidValue;
-  if ((epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) &&
-      (a.rowstat == nullptr || a.colsum == nullptr || a.bias == nullptr))
-    return hipErrorInvalidValue;
+  if (epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) {
+    if (a.colsum == nullptr || a.bias == nullptr) return hipErrorInvalidValue;
+    if (gemm_uses_persistent(a.M, a.N, a.K)
+            ? (a.rowpart_in == nullptr || a.nparts < 1 || a.nparts > kRowParts)
+            : a.rowstat == nullptr)
+      return hipErrorInvalidValue;
+  }
   if (dtype16 == DT_F16) return launch_epi<f16_t>(epi, a, s);
   if (dtype16 == DT_BF16) return launch_epi<bf16_t>(epi, a, s);
   return hipErrorInvalidValue;

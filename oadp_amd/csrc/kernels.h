@@ -37,9 +37,18 @@ struct GemmArgs {
   // EPI_*_LN only
   const float* rowstat;  // [M + 1, 2] (rstd, -mean * rstd) of the raw A rows (launch_rowstat; row M is padding)
   const float* colsum;   // [N] sum_k W[n,k]
+  // Row statistics handed from GEMM to GEMM when both run the persistent kernel
+  // (gemm_uses_persistent): EPI_RESID16 writes (sum x, sum x^2) of each 64-column slice of its
+  // output rows to rowpart_out [M, 16, 2] (nullptr: don't); EPI_*_LN reads the first `nparts`
+  // slices of rowpart_in [M, 16, 2] instead of `rowstat`.
+  float* rowpart_out;
+  const float* rowpart_in;
+  int nparts;
 };
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
+// true when launch_gemm runs this shape on the persistent kernel (row statistics via rowpart_*)
+bool gemm_uses_persistent(int M, int N, int K);
 
 // ---- row kernels -------------------------------------------------------------------------
 // y(16-bit)[rows,c] = LN(x [rows, c]); x is fp32 (x_dtype DT_F32) or the 16-bit type (x_dtype ==
@@ -57,9 +66,13 @@ hipError_t launch_fold_ln(int dtype16, const float* w32, const float* gamma, con
                           hipStream_t s);
 
 // x[n*L + t, :] (in place, fp32 or 16-bit): t == 0 -> cls + pos[0]; then ln_pre over every row.
+// rowpart (optional): [n*L, 16, 2] — slot 0 of each row receives (sum, sum of squares) of the output row
 hipError_t launch_embed_ln_pre(void* x, int x_dtype, const float* cls, const float* pos,
                                const float* gamma, const float* beta, int n, int L, int c,
-                               hipStream_t s);
+                               float* rowpart, hipStream_t s);
+// rowpart[row][0] = (sum, sum of squares) of x[row, :c]   (tests / debug entry)
+hipError_t launch_rowsums(const void* x, int x_dtype, long x_row_stride, float* rowpart, int rows,
+                          int c, hipStream_t s);
 
 // y[n, :] (fp32) = x[n*L + 0, :]  (objects mode: object-token stream starts as the CLS row)
 hipError_t launch_copy_cls(const void* x, int x_dtype, float* y, int n, int L, int c, hipStream_t s);

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TX* __restrict__ x
 // and its epilogue applies the two per-row scalars below, so the normalised activations are never
 // written to / re-read from HBM (2 x 19.7 MB per LayerNorm at bs 256) — only these 8 B per row.
 // stat[row] = (rstd, -mean * rstd); statistics of the row exactly as the GEMM will read it.
-template <typename TX>
+// (SUMS: stat[row * 16] = (sum x, sum x^2) instead — slot 0 of the GEMM-to-GEMM row-statistics
+// buffer, see kernels.h GemmArgs::rowpart_in)
+template <typename TX, bool SUMS>
 __global__ __launch_bounds__(256) void rowstat_kernel(const TX* __restrict__ x, long stride,
                                                       float2* __restrict__ stat, int rows, int c) {
   const int lane = threadIdx.x & 63;
@@ -98,9 +100,22 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const TX* __restrict__ x, 
 #pragma unroll
   for (int i = 0; i < kMaxVec; ++i)
     if (lane + 64 * i < nv) v[i] = load4<TX>(xr, lane + 64 * i);
-  float mean, rstd;
-  ln_stats(v, lane, nv, c, mean, rstd);
-  if (lane == 0) stat[row] = make_float2(rstd, -mean * rstd);
+  if constexpr (SUMS) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i)
+      if (lane + 64 * i < nv) {
+        s1 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        s2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) stat[(size_t)row * 16] = make_float2(s1, s2);
+  } else {
+    float mean, rstd;
+    ln_stats(v, lane, nv, c, mean, rstd);
+    if (lane == 0) stat[row] = make_float2(rstd, -mean * rstd);
+  }
 }
 
 // One wave per output feature n:  wf[n,:] = T(w32[n,:] * gamma),  colsum[n] = sum_k wf[n,k] (the
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(TX* __restrict__ x,
                                                            const float* __restrict__ pos,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int rows,
-                                                           int L, int c) {
+                                                           int L, int c, float2* __restrict__ rowpart) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -166,13 +181,23 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(TX* __restrict__ x,
   ln_stats(v, lane, nv, c, mean, rstd);
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < kMaxVec; ++i)
     if (lane + 64 * i < nv) {
       const float4 g = g4[lane + 64 * i], b = b4[lane + 64 * i];
-      store4<TX>(xr, lane + 64 * i, (v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                 (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y;
+      const float o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
+      store4<TX>(xr, lane + 64 * i, o0, o1, o2, o3);
+      s1 += (o0 + o1) + (o2 + o3);
+      s2 += (o0 * o0 + o1 * o1) + (o2 * o2 + o3 * o3);
     }
+  // layer 0's ln_1 statistics ride along (slot 0 of the GEMM-to-GEMM row-statistics buffer)
+  if (rowpart != nullptr) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) rowpart[(size_t)row * 16] = make_float2(s1, s2);
+  }
 }
 
 template <typename TX>
@@ -349,14 +374,34 @@ hipError_t launch_rowstat(const void* x, int x_dtype, long x_row_stride, float* 
   const dim3 g((rows + 3) / 4), b(256);
   float2* st = reinterpret_cast<float2*>(stat);
   if (x_dtype == DT_F32)
-    hipLaunchKernelGGL((rowstat_kernel<float>), g, b, 0, s, reinterpret_cast<const float*>(x),
+    hipLaunchKernelGGL((rowstat_kernel<float, false>), g, b, 0, s, reinterpret_cast<const float*>(x),
                        x_row_stride, st, rows, c);
   else if (x_dtype == DT_F16)
-    hipLaunchKernelGGL((rowstat_kernel<f16_t>), g, b, 0, s, reinterpret_cast<const f16_t*>(x),
+    hipLaunchKernelGGL((rowstat_kernel<f16_t, false>), g, b, 0, s, reinterpret_cast<const f16_t*>(x),
                        x_row_stride, st, rows, c);
   else if (x_dtype == DT_BF16)
-    hipLaunchKernelGGL((rowstat_kernel<bf16_t>), g, b, 0, s, reinterpret_cast<const bf16_t*>(x),
+    hipLaunchKernelGGL((rowstat_kernel<bf16_t, false>), g, b, 0, s, reinterpret_cast<const bf16_t*>(x),
                        x_row_stride, st, rows, c);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_rowsums(const void* x, int x_dtype, long x_row_stride, float* rowpart, int rows,
+                          int c, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
+  const dim3 g((rows + 3) / 4), b(256);
+  float2* st = reinterpret_cast<float2*>(rowpart);
+  if (x_dtype == DT_F32)
+    hipLaunchKernelGGL((rowstat_kernel<float, true>), g, b, 0, s, reinterpret_cast<const float*>(x),
+                       x_row_stride, st, rows, c);
+  else if (x_dtype == DT_F16)
+    hipLaunchKernelGGL((rowstat_kernel<f16_t, true>), g, b, 0, s, reinterpret_cast<const f16_t*>(x),
+                       x_row_stride, st, rows, c);
+  else if (x_dtype == DT_BF16)
+    hipLaunchKernelGGL((rowstat_kernel<bf16_t, true>), g, b, 0, s,
+                       reinterpret_cast<const bf16_t*>(x), x_row_stride, st, rows, c);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
@@ -380,20 +425,20 @@ hipError_t launch_fold_ln(int dtype16, const float* w32, const float* gamma, con
 
 hipError_t launch_embed_ln_pre(void* x, int x_dtype, const float* cls, const float* pos,
                                const float* gamma, const float* beta, int n, int L, int c,
-                               hipStream_t s) {
+                               float* rowpart, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
   const int rows = n * L;
   const dim3 g((rows + 3) / 4), b(256);
   if (x_dtype == DT_F32)
     hipLaunchKernelGGL(embed_ln_pre_kernel<float>, g, b, 0, s, reinterpret_cast<float*>(x), cls, pos,
-                       gamma, beta, rows, L, c);
+                       gamma, beta, rows, L, c, reinterpret_cast<float2*>(rowpart));
   else if (x_dtype == DT_F16)
     hipLaunchKernelGGL(embed_ln_pre_kernel<f16_t>, g, b, 0, s, reinterpret_cast<f16_t*>(x), cls, pos,
-                       gamma, beta, rows, L, c);
+                       gamma, beta, rows, L, c, reinterpret_cast<float2*>(rowpart));
   else if (x_dtype == DT_BF16)
     hipLaunchKernelGGL(embed_ln_pre_kernel<bf16_t>, g, b, 0, s, reinterpret_cast<bf16_t*>(x), cls,
-                       pos, gamma, beta, rows, L, c);
+                       pos, gamma, beta, rows, L, c, reinterpret_cast<float2*>(rowpart));
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -56,6 +56,21 @@ def test_encode_image_vit_b32(cuda, resid32):
     _check(out16, ref16, 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
+def test_encode_image_vit_b32_production_kernels(cuda, dtype, tol):
+    """48 crops x 50 tokens = 2400 rows: large enough that every main-stream GEMM runs the
+    persistent kernel with the LayerNorm folded in and the row statistics handed from the residual
+    epilogue to the next GEMM (csrc/gemm.hip) — the path bench.py measures; 45 crops leave a ragged
+    last tile (2250 = 14 * 160 + 10)."""
+    sd = synthetic_state_dict()
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48)
+    for n in (48, 45):
+        x = synthetic_images(n, seed=100 + n)
+        ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
+        out = model.encode_image(x.to(cuda), normalize=True, out_dtype=torch.float32)
+        _check(out, ref, tol, tol)
+
+
 def test_encode_image_batch_invariance(cuda):
     """The per-image .pth contract: an image's feature must not depend on its batch."""
     sd = synthetic_state_dict(**TINY)
