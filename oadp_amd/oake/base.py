@@ -12,6 +12,8 @@ import argparse
 import json
 import os
 import pathlib
+import queue
+import threading
 import time
 from abc import ABC, abstractmethod
 from typing import Any, Generic, Iterable, Protocol, TypeVar
@@ -122,6 +124,72 @@ def atomic_save(obj: Any, path: pathlib.Path) -> None:
     os.replace(tmp, path)
 
 
+class AsyncWriter:
+    """Background ``atomic_save``: the reference writes one small file per
+    image synchronously on the thread that also drives the GPU (oadp/oake/base.py:112); at 10^4-10^5
+    images/s per GPU that serialises the whole sweep.  ``threads`` workers take (object, path)
+    pairs from a bounded queue; ``drain()`` blocks until everything is on disk and re-raises the first
+    worker error.  ``threads=0`` degenerates to the synchronous behaviour."""
+
+    def __init__(self, threads: int = 4, depth: int = 4096) -> None:
+        self.bytes = 0
+        self._threads: list[threading.Thread] = []
+        self._error: BaseException | None = None
+        self._lock = threading.Lock()
+        self._queue: queue.Queue | None = queue.Queue(maxsize=depth) if threads > 0 else None
+        for i in range(threads):
+            t = threading.Thread(target=self._work, name=f'oake-writer-{i}', daemon=True)
+            t.start()
+            self._threads.append(t)
+
+    def _save(self, obj: Any, path: pathlib.Path) -> None:
+        atomic_save(obj, path)
+        size = path.stat().st_size
+        with self._lock:
+            self.bytes += size
+
+    def _work(self) -> None:
+        assert self._queue is not None
+        while True:
+            item = self._queue.get()
+            try:
+                if item is None:
+                    return
+                if self._error is None:
+                    self._save(*item)
+            except BaseException as e:  # noqa: BLE001 — surfaced by drain()
+                with self._lock:
+                    self._error = self._error or e
+            finally:
+                self._queue.task_done()
+
+    def submit(self, obj: Any, path: pathlib.Path) -> None:
+        if self._error is not None:
+            self.drain()
+        if self._queue is None:
+            self._save(obj, path)
+        else:
+            self._queue.put((obj, path))
+
+    def drain(self) -> None:
+        if self._queue is not None:
+            self._queue.join()
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
+
+    def close(self) -> None:
+        try:
+            self.drain()
+        finally:
+            if self._queue is not None:
+                for _ in self._threads:
+                    self._queue.put(None)
+                for t in self._threads:
+                    t.join()
+                self._threads.clear()
+
+
 class Counters:
     """[images, crops, seconds, bytes] — the only thing exchanged between ranks."""
 
@@ -150,7 +218,7 @@ class BaseValidator(ABC, Generic[T]):
 
     def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
                  batch_size: int = 256, device: torch.device | str | None = None,
-                 **kwargs) -> None:
+                 writer_threads: int = 4, **kwargs) -> None:
         self.name = name
         self._model = model
         self._log_interval = (log or {}).get('interval', 50)
@@ -159,6 +227,8 @@ class BaseValidator(ABC, Generic[T]):
             device = torch.device('cuda', torch.cuda.current_device()) if Store.CUDA else 'cpu'
         self._device = torch.device(device)
         self.counters = Counters()
+        self._writer_threads = writer_threads
+        self._writer: AsyncWriter | None = None
         self._dataloader = self._build_dataloader(Config(dataloader))
 
     # -- reference surface ----------------------------------------------------------------------
@@ -189,16 +259,31 @@ class BaseValidator(ABC, Generic[T]):
         if not pending:
             return
         results = self._encode(pending)
+        assert self._writer is not None
         for batch, result in zip(pending, results):
-            atomic_save(result, batch.output)
+            self._writer.submit(result, batch.output)
             self.counters.images += 1
-            self.counters.bytes += batch.output.stat().st_size
         pending.clear()
 
     def run(self) -> Counters:
         t0 = time.perf_counter()
         pending: list[T] = []
         crops = 0
+        self._writer = AsyncWriter(self._writer_threads)
+        try:
+            self._run_loop(pending, crops)
+        finally:
+            writer, self._writer = self._writer, None
+            try:
+                writer.close()  # every file of this split is on disk (or the error is raised) here
+            finally:
+                self.counters.bytes += writer.bytes
+        if self._device.type == 'cuda':
+            torch.cuda.synchronize(self._device)
+        self.counters.seconds += time.perf_counter() - t0
+        return self.counters
+
+    def _run_loop(self, pending: list[T], crops: int) -> None:
         for i, batch in enumerate(self._dataloader):
             if batch is None:  # reference _control_run_iter: CONTINUE on None (base.py:96-104)
                 continue
@@ -213,10 +298,6 @@ class BaseValidator(ABC, Generic[T]):
                       f'images {self.counters.images} crops {self.counters.crops}', flush=True)
         self.counters.crops += crops
         self._flush(pending)
-        if self._device.type == 'cuda':
-            torch.cuda.synchronize(self._device)
-        self.counters.seconds += time.perf_counter() - t0
-        return self.counters
 
     @classmethod
     def main(cls, argv: list[str] | None = None) -> None:

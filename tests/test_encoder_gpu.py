@@ -71,6 +71,27 @@ def test_encode_image_vit_b32_production_kernels(cuda, dtype, tol):
         _check(out, ref, tol, tol)
 
 
+def test_encode_image_full_size_properties(cuda):
+    """BASELINE.json configs[1] at its full size (ViT-B/32, 256 crops): size-independent properties.
+    Splitting or permuting the batch must not change any image's feature bit-wise (rows are
+    independent through every kernel; all of these shapes run the same persistent kernels), the
+    features are unit vectors, and a subset agrees with the oracle."""
+    sd = synthetic_state_dict()
+    model, _ = clip.load(sd, max_batch=256)
+    x = synthetic_images(256, seed=77).to(cuda)
+    full = model.encode_image(x, normalize=True, out_dtype=torch.float16)
+    assert full.shape == (256, 512) and torch.isfinite(full.float()).all()
+    assert (full.float().norm(dim=1) - 1).abs().max().item() < 2e-3
+    halves = torch.cat([model.encode_image(x[:128], normalize=True, out_dtype=torch.float16),
+                        model.encode_image(x[128:], normalize=True, out_dtype=torch.float16)])
+    assert torch.equal(full, halves)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(5)).to(cuda)
+    assert torch.equal(model.encode_image(x[perm], normalize=True, out_dtype=torch.float16), full[perm])
+    idx = [0, 63, 130, 255]
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x[idx].cpu()))
+    _check(full[idx].float(), ref, 1e-3, 1e-3)
+
+
 def test_encode_image_batch_invariance(cuda):
     """The per-image .pth contract: an image's feature must not depend on its batch."""
     sd = synthetic_state_dict(**TINY)

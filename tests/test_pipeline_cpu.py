@@ -165,3 +165,26 @@ td.destroy_process_group()
     # twice or skipped by the resume rule, depending on timing
     assert 'GATHER 2 6' in r.stdout or 'GATHER 2 5' in r.stdout, r.stdout
     assert sorted(int(p.stem) for p in out.iterdir()) == coco['ids']
+
+
+@pytest.mark.parametrize('threads', [0, 3])
+def test_async_writer_contract(tmp_path, threads):
+    """AsyncWriter: every submitted payload is on disk and loadable after close(),
+    no temporary files remain, byte count matches, and a worker error surfaces in drain()."""
+    from oadp_amd.oake.base import AsyncWriter
+    w = AsyncWriter(threads)
+    payloads = {i: torch.full((512,), float(i)).half() for i in range(200)}
+    for i, t in payloads.items():
+        w.submit(t, tmp_path / f'{i:012d}.pth')
+    w.close()
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert files == [f'{i:012d}.pth' for i in range(200)]
+    assert w.bytes == sum((tmp_path / f).stat().st_size for f in files)
+    for i in (0, 57, 199):
+        assert torch.equal(torch.load(tmp_path / f'{i:012d}.pth', 'cpu'), payloads[i])
+
+    w = AsyncWriter(threads)
+    with pytest.raises((FileNotFoundError, RuntimeError, OSError)):
+        w.submit(payloads[0], tmp_path / 'no_such_dir' / 'x.pth')
+        w.drain()
+    w.close()
