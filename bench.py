@@ -156,7 +156,8 @@ def main() -> None:
             'mfma_roofline_frac_e2e': round(value / world * FLOP_PER_IMAGE / PEAK_MFMA_DENSE, 4),
             'roofline': roofline,
             'kernels': kernels,
-            'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(sd),
+            # (rank 0 at N=1 only: with more ranks the other processes would sit in teardown for its 10+ s)
+            'cpu_baseline': None if (args.no_cpu_baseline or world > 1) else cpu_baseline(sd),
         }
         print(json.dumps(line), flush=True)
     if dist:
