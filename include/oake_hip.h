@@ -55,7 +55,8 @@ enum {
   OAKE_ERR_INVALID = 1,   /* bad argument / shape / dtype */
   OAKE_ERR_HIP = 2,       /* a HIP runtime call failed; see oake_last_error */
   OAKE_ERR_STATE = 3,     /* e.g. encode before all weights were loaded */
-  OAKE_ERR_UNKNOWN_TENSOR = 4
+  OAKE_ERR_UNKNOWN_TENSOR = 4,
+  OAKE_ERR_UNSUPPORTED = 5  /* valid input outside the implemented subset (e.g. progressive JPEG) */
 };
 
 /* element types for image inputs / embedding outputs */
@@ -176,6 +177,23 @@ OAKE_API int oake_crop_resize_normalize(oake_handle* h, const uint8_t* d_image_h
  * oadp/oake/blocks.py:72-76 — bit-exact with Pillow. */
 OAKE_API int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw,
                    uint8_t* d_dst_hwc, int dh, int dw, void* stream);
+
+/*
+ * Baseline JPEG -> uint8 HWC RGB on the device, bit-identical to
+ * PIL.Image.open(...).convert('RGB') (libjpeg-turbo defaults: islow IDCT, fancy upsampling) — the
+ * decode of torchvision CocoDetection._load_image behind oadp/oake/base.py:53.  The Huffman pass runs
+ * on the calling host thread, IDCT / upsampling / colour conversion on `stream`.  h_data is a HOST
+ * buffer holding the whole file.  Progressive / arithmetic / CMYK / 12-bit files return
+ * OAKE_ERR_UNSUPPORTED (decode those with PIL and upload the pixels instead).
+ * oake_jpeg_info needs no handle and no GPU.
+ */
+OAKE_API int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width, int* components);
+OAKE_API int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8_t* d_out_hwc,
+                     size_t out_capacity, int* height, int* width, void* stream);
+/* Host half only (tests; no handle, no GPU): the quantised DCT coefficients of every component,
+ * [component][block row][block column][64] in natural order, MCU-padded.  h_coefs NULL: size query. */
+OAKE_API int oake_debug_jpeg_coefs(const uint8_t* h_data, size_t nbytes, int16_t* h_coefs, size_t capacity,
+                          size_t* total);
 
 /*
  * Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).

@@ -7,6 +7,7 @@ import os
 import pathlib
 
 OAKE_OK = 0
+OAKE_ERR_INVALID, OAKE_ERR_HIP, OAKE_ERR_STATE, OAKE_ERR_UNKNOWN_TENSOR, OAKE_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
 ABI_VERSION = 1
 
@@ -44,6 +45,9 @@ SIGNATURES = {
     'oake_crop_resize_normalize': (_I, [_VP, _VP, _I, _I, C.POINTER(C.c_float), _I, _I, _I,
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), _VP, _I, _VP]),
     'oake_resize_u8': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
+    'oake_jpeg_info': (_I, [_VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'oake_debug_jpeg_coefs': (_I, [_VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    'oake_decode_jpeg': (_I, [_VP, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
     'oake_profile_enable': (_I, [_VP, _I]),
     'oake_profile_read': (_I, [_VP, C.POINTER(ProfileEntry), _I, C.POINTER(_I)]),
     'oake_profile_reset': (_I, [_VP]),

@@ -18,7 +18,7 @@ ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
-SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip', 'resample.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
 HEADERS = ['common.h', 'kernels.h', '../../include/oake_hip.h']
 ARCH = 'gfx950'
 FLAGS = [

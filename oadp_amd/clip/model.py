@@ -246,6 +246,27 @@ class VisionTransformer:
             _lib.check(self._lib, h, rc, 'oake_resize_u8')
         return out
 
+    def decode_jpeg(self, data: bytes, device: torch.device | None = None) -> torch.Tensor:
+        """Baseline JPEG file bytes -> uint8 HWC RGB device tensor, bit-identical to
+        ``PIL.Image.open(...).convert('RGB')`` (the decode behind oadp/oake/base.py:53).  Huffman
+        decoding runs on the calling thread, IDCT / upsampling / colour conversion on the GPU.
+        Raises ``OakeError`` for files outside the supported subset (progressive, CMYK, ...)."""
+        dev = torch.device(device).index if device is not None else None
+        dev = torch.cuda.current_device() if dev is None else dev
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        hh, ww = C.c_int(0), C.c_int(0)
+        rc = self._lib.oake_jpeg_info(buf, len(data), C.byref(hh), C.byref(ww), None)
+        if rc != _lib.OAKE_OK:
+            raise _lib.OakeError('oake_jpeg_info: ' + ('unsupported JPEG variant' if rc == _lib.OAKE_ERR_UNSUPPORTED
+                                                       else 'not a valid JPEG'))
+        out = torch.empty((hh.value, ww.value, 3), dtype=torch.uint8, device=torch.device('cuda', dev))
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            rc = self._lib.oake_decode_jpeg(h, buf, len(data), out.data_ptr(), out.numel(), C.byref(hh),
+                                            C.byref(ww), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_decode_jpeg')
+        return out
+
     def crop_normalize(self, image_u8: torch.Tensor, boxes_xyxy, *,
                        out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
         """Exact-size (n x n) integer crops + ToTensor + Normalize (blocks of one pyramid level)."""

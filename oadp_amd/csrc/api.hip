@@ -101,6 +101,13 @@ struct oake_handle {
   uint8_t* rs_temp = nullptr;
   size_t rs_jobs_cap = 0, rs_coef_cap = 0, rs_bounds_cap = 0, rs_temp_cap = 0;
 
+  // JPEG decode scratch (grown on demand): pinned host coefficients, device coefficients + planes
+  int16_t* jp_host = nullptr;
+  int16_t* jp_coefs = nullptr;
+  uint8_t* jp_planes = nullptr;
+  size_t jp_host_cap = 0, jp_coefs_cap = 0, jp_planes_cap = 0;
+  hipEvent_t jp_copied = nullptr;  // the last upload out of jp_host has completed
+
   // profiler
   bool prof = false;
   std::vector<ProfSlot> slots;
@@ -252,7 +259,7 @@ void oake_destroy(oake_handle* h) {
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
                   h->yn, h->qkv_y, h->att_y, h->h_y, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
-                  h->rowstat, h->rowpart};
+                  h->rowstat, h->rowpart, h->jp_coefs, h->jp_planes};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& l : h->layers) {
@@ -262,6 +269,8 @@ void oake_destroy(oake_handle* h) {
     for (void* p : lp)
       if (p) (void)hipFree(p);
   }
+  if (h->jp_host) (void)hipHostFree(h->jp_host);
+  if (h->jp_copied) (void)hipEventDestroy(h->jp_copied);
   prof_collect(h);
   for (auto e : h->evt_pool) (void)hipEventDestroy(e);
   delete h;
@@ -827,6 +836,72 @@ int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw, uin
   j.sx0 = j.sy0 = 0; j.cw = sw; j.ch = sh; j.rw = dw; j.rh = dh; j.cx = j.cy = 0;
   const float z[3] = {0.f, 0.f, 0.f}, o[3] = {1.f, 1.f, 1.f};
   return run_resample(h, s, d_src_hwc, sh, sw, jobs, 0, z, o, d_dst_hwc, OAKE_U8);
+}
+
+int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width, int* components) {
+  if (!h_data) return OAKE_ERR_INVALID;
+  JpegFrame f;
+  const int rc = jpeg_read_frame(h_data, nbytes, &f, nullptr);
+  if (rc == JPEG_UNSUPPORTED) return OAKE_ERR_UNSUPPORTED;
+  if (rc != JPEG_OK) return OAKE_ERR_INVALID;
+  if (height) *height = f.height;
+  if (width) *width = f.width;
+  if (components) *components = f.ncomp;
+  return OAKE_OK;
+}
+
+int oake_debug_jpeg_coefs(const uint8_t* h_data, size_t nbytes, int16_t* h_coefs, size_t capacity,
+                          size_t* total) {
+  if (!h_data) return OAKE_ERR_INVALID;
+  JpegFrame f;
+  int rc = jpeg_read_frame(h_data, nbytes, &f, nullptr);
+  if (rc == JPEG_UNSUPPORTED) return OAKE_ERR_UNSUPPORTED;
+  if (rc != JPEG_OK) return OAKE_ERR_INVALID;
+  if (total) *total = (size_t)f.total_coefs;
+  if (!h_coefs) return OAKE_OK;
+  if (capacity < (size_t)f.total_coefs) return OAKE_ERR_INVALID;
+  rc = jpeg_decode_coefs(h_data, nbytes, f, h_coefs, nullptr);
+  return rc == JPEG_OK ? OAKE_OK : (rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID);
+}
+
+int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8_t* d_out_hwc,
+                     size_t out_capacity, int* height, int* width, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (!h_data || !d_out_hwc) return fail(h, OAKE_ERR_INVALID, "null pointer");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  JpegFrame f;
+  std::string err;
+  int rc = jpeg_read_frame(h_data, nbytes, &f, &err);
+  if (rc != JPEG_OK)
+    return fail(h, rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID, "jpeg: " + err);
+  if (height) *height = f.height;
+  if (width) *width = f.width;
+  if ((size_t)f.height * f.width * 3 > out_capacity)
+    return fail(h, OAKE_ERR_INVALID, "jpeg: output buffer too small");
+  const size_t cbytes = (size_t)f.total_coefs * sizeof(int16_t);
+  if (!h->jp_copied) HIP_TRY(h, hipEventCreateWithFlags(&h->jp_copied, hipEventDisableTiming));
+  if (cbytes > h->jp_host_cap) {
+    HIP_TRY(h, hipEventSynchronize(h->jp_copied));
+    if (h->jp_host) HIP_TRY(h, hipHostFree(h->jp_host));
+    h->jp_host = nullptr;
+    h->jp_host_cap = 0;
+    const size_t cap = cbytes + cbytes / 4 + 4096;
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->jp_host), cap, hipHostMallocDefault));
+    h->jp_host_cap = cap;
+  }
+  if ((rc = grow(h, s, &h->jp_coefs, &h->jp_coefs_cap, cbytes))) return rc;
+  if ((rc = grow(h, s, &h->jp_planes, &h->jp_planes_cap, (size_t)f.total_plane_bytes))) return rc;
+  // the previous image's coefficients must have left the pinned buffer before it is rewritten
+  HIP_TRY(h, hipEventSynchronize(h->jp_copied));
+  rc = jpeg_decode_coefs(h_data, nbytes, f, h->jp_host, &err);
+  if (rc != JPEG_OK)
+    return fail(h, rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID, "jpeg: " + err);
+  HIP_TRY(h, hipMemcpyAsync(h->jp_coefs, h->jp_host, cbytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipEventRecord(h->jp_copied, s));
+  RUN(h, s, "jpeg_reconstruct", 0.0, (double)cbytes + 2.0 * f.total_plane_bytes + 3.0 * f.height * f.width,
+      launch_jpeg_reconstruct(f, h->jp_coefs, h->jp_planes, d_out_hwc, s));
+  return OAKE_OK;
 }
 
 int oake_profile_enable(oake_handle* h, int enable) {

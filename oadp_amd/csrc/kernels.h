@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace oake {
 
 // 16-bit operand type selector (matches OAKE_F16 / OAKE_BF16 in include/oake_hip.h)
@@ -124,6 +126,26 @@ hipError_t launch_resample(const uint8_t* img, int height, int width, const Resa
                            int njobs, int max_out, int max_ch_rw, int32_t* d_coef, int32_t* d_bounds,
                            uint8_t* d_temp, int out_size, const float* mean3, const float* std3,
                            void* out, int out_dtype, hipStream_t s);
+
+// ---- baseline JPEG decode (jpeg.hip) ---------------------------------------------------------
+enum { JPEG_OK = 0, JPEG_INVALID = 1, JPEG_UNSUPPORTED = 2 };
+struct JpegFrame {
+  int width, height, ncomp, hmax, vmax, mcux, mcuy;
+  int h[3], v[3];            // sampling factors
+  int bx[3], by[3];          // blocks per row / column of each (MCU-padded) component plane
+  long coef_off[3];          // int16 element offset of each component's [by][bx][64] coefficients
+  long plane_off[3];         // byte offset of each component's uint8 plane [by*8][bx*8]
+  long total_coefs, total_plane_bytes;
+  uint16_t q[3][64];         // quantisation table of each component, natural (row-major) order
+};
+// header walk only (dimensions, sampling, buffer sizes); host
+int jpeg_read_frame(const uint8_t* data, size_t n, JpegFrame* frame, std::string* err);
+// host Huffman decode of the single interleaved scan into coefs[total_coefs] (natural order)
+int jpeg_decode_coefs(const uint8_t* data, size_t n, const JpegFrame& frame, int16_t* coefs,
+                      std::string* err);
+// dequantise + IDCT into d_planes[total_plane_bytes], then upsample + colour-convert to HWC RGB
+hipError_t launch_jpeg_reconstruct(const JpegFrame& frame, const int16_t* d_coefs, uint8_t* d_planes,
+                                   uint8_t* d_out_hwc, hipStream_t s);
 
 hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s);
 

@@ -1,0 +1,138 @@
+"""JPEG decode: oracle pinned to Pillow, host Huffman pass pinned to the oracle (CPU),
+device reconstruction pinned to Pillow (GPU)."""
+import ctypes as C
+import io
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import jpeg_ref
+
+
+def _synth(h, w, kind, seed=0):
+    rng = np.random.default_rng(seed + h * 131 + w)
+    if kind == 'noise':
+        return (rng.random((h, w, 3)) * 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.stack([(xx * 7 + yy * 3) % 256, (xx * 2 + yy * 5 + 40) % 256, (xx * yy) % 256], -1)
+    return smooth.astype(np.uint8)
+
+
+def _encode(a, **kw):
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, 'JPEG', **kw)
+    return b.getvalue()
+
+
+def _pil(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
+
+
+CASES = [(h, w, ss, q, kind)
+         for (h, w) in [(8, 8), (1, 1), (7, 9), (17, 33), (37, 53), (64, 48), (33, 16)]
+         for ss in (0, 1, 2) for q in (30, 90) for kind in ('noise', 'grad')]
+
+
+@pytest.mark.parametrize('h,w,ss,q,kind', CASES)
+def test_oracle_matches_pillow(h, w, ss, q, kind):
+    data = _encode(_synth(h, w, kind), quality=q, subsampling=ss)
+    assert np.array_equal(jpeg_ref.decode(data), _pil(data))
+
+
+def test_oracle_grayscale_optimized_restart():
+    g = (np.random.default_rng(3).random((21, 35)) * 255).astype(np.uint8)
+    data = _encode(g, quality=80)
+    assert np.array_equal(jpeg_ref.decode(data), _pil(data))
+    a = _synth(45, 70, 'grad')
+    data = _encode(a, quality=85, optimize=True)  # image-specific Huffman tables
+    assert np.array_equal(jpeg_ref.decode(data), _pil(data))
+    data = _encode(a, quality=85, subsampling=2, restart_marker_blocks=3)
+    assert b'\xff\xdd' in data  # DRI present
+    assert np.array_equal(jpeg_ref.decode(data), _pil(data))
+
+
+def test_oracle_rejects_progressive():
+    data = _encode(_synth(16, 16, 'grad'), quality=80, progressive=True)
+    with pytest.raises(NotImplementedError):
+        jpeg_ref.decode(data)
+
+
+def _host_coefs(lib, data):
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    total = C.c_size_t(0)
+    rc = lib.oake_debug_jpeg_coefs(buf, len(data), None, 0, C.byref(total))
+    assert rc == 0
+    out = np.zeros(total.value, np.int16)
+    rc = lib.oake_debug_jpeg_coefs(buf, len(data), out.ctypes.data_as(C.c_void_p), out.size, C.byref(total))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize('h,w,ss,q,kind', CASES[::3])
+def test_host_huffman_pass_matches_oracle(h, w, ss, q, kind):
+    """The C++ entropy decoder of liboake_hip.so (no GPU involved) against the oracle's coefficients."""
+    from oadp_amd import _lib
+    lib = _lib.load()
+    data = _encode(_synth(h, w, kind), quality=q, subsampling=ss)
+    _, _, _, _, planes = jpeg_ref.parse(data)
+    ref = np.concatenate([p.reshape(-1) for p in planes]).astype(np.int16)
+    assert np.array_equal(_host_coefs(lib, data), ref)
+
+
+def test_host_huffman_restart_optimized_info():
+    from oadp_amd import _lib
+    lib = _lib.load()
+    a = _synth(45, 70, 'noise')
+    for kw in (dict(quality=85, optimize=True), dict(quality=70, subsampling=2, restart_marker_blocks=2),
+               dict(quality=95, subsampling=1, restart_marker_rows=1)):
+        data = _encode(a, **kw)
+        _, _, _, _, planes = jpeg_ref.parse(data)
+        ref = np.concatenate([p.reshape(-1) for p in planes]).astype(np.int16)
+        assert np.array_equal(_host_coefs(lib, data), ref)
+        hh, ww, cc = C.c_int(), C.c_int(), C.c_int()
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        assert lib.oake_jpeg_info(buf, len(data), C.byref(hh), C.byref(ww), C.byref(cc)) == 0
+        assert (hh.value, ww.value, cc.value) == (45, 70, 3)
+    prog = _encode(a, quality=80, progressive=True)
+    buf = (C.c_uint8 * len(prog)).from_buffer_copy(prog)
+    assert lib.oake_jpeg_info(buf, len(prog), None, None, None) == _lib.OAKE_ERR_UNSUPPORTED
+    junk = bytes(100)
+    buf = (C.c_uint8 * len(junk)).from_buffer_copy(junk)
+    assert lib.oake_jpeg_info(buf, len(junk), None, None, None) == _lib.OAKE_ERR_INVALID
+
+
+GPU_CASES = [(480, 640, 2, 85, 'grad'), (427, 640, 2, 75, 'noise'), (333, 500, 1, 90, 'grad'),
+             (224, 224, 0, 95, 'noise'), (1, 1, 2, 50, 'grad'), (17, 33, 2, 60, 'noise'), (9, 7, 1, 60, 'noise'),
+             (1134, 1700, 2, 80, 'grad')]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w,ss,q,kind', GPU_CASES)
+def test_device_decode_matches_pillow(cuda, h, w, ss, q, kind):
+    """oake_decode_jpeg through the C ABI: every pixel equal to PIL.Image.open().convert('RGB')."""
+    from oadp_amd import clip
+    from oadp_amd.weights import synthetic_state_dict
+    from tests._synth import TINY
+    model, _ = clip.load(synthetic_state_dict(**TINY), max_batch=2)
+    data = _encode(_synth(h, w, kind), quality=q, subsampling=ss)
+    out = model.visual.decode_jpeg(data)
+    assert out.dtype == torch.uint8 and out.shape == (h, w, 3) and out.is_cuda
+    assert np.array_equal(out.cpu().numpy(), _pil(data))
+
+
+@pytest.mark.gpu
+def test_device_decode_gray_restart_errors(cuda):
+    from oadp_amd import clip, _lib
+    from oadp_amd.weights import synthetic_state_dict
+    from tests._synth import TINY
+    model, _ = clip.load(synthetic_state_dict(**TINY), max_batch=2)
+    g = (np.random.default_rng(3).random((121, 235)) * 255).astype(np.uint8)
+    for data in (_encode(g, quality=80), _encode(_synth(90, 130, 'noise'), quality=85, optimize=True),
+                 _encode(_synth(90, 130, 'grad'), quality=70, subsampling=2, restart_marker_blocks=5)):
+        assert np.array_equal(model.visual.decode_jpeg(data).cpu().numpy(), _pil(data))
+    with pytest.raises(_lib.OakeError):
+        model.visual.decode_jpeg(_encode(_synth(32, 32, 'grad'), quality=80, progressive=True))
+    with pytest.raises(_lib.OakeError):
+        model.visual.decode_jpeg(b'not a jpeg at all')
