@@ -52,11 +52,34 @@ class CocoImages:
         return [self.imgs[i] for i in ids]
 
 
+class EncodedImage:
+    """Stands in for the PIL image on the device-decode path: the host only knows the size."""
+
+    def __init__(self, data: bytes, size: tuple[int, int]) -> None:
+        self.data = data
+        self.size = size  # (width, height), as PIL.Image.size
+
+
+def jpeg_size(data: bytes) -> tuple[int, int] | None:
+    """(width, height) if ``oake_decode_jpeg`` can decode this file, else None (no GPU involved)."""
+    import ctypes as C
+
+    from .. import _lib
+    lib = _lib.load()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    h, w = C.c_int(0), C.c_int(0)
+    if lib.oake_jpeg_info(buf, len(data), C.byref(h), C.byref(w), None) != _lib.OAKE_OK:
+        return None
+    return w.value, h.value
+
+
 class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
     _device_preprocess = False
+    _device_decode: bool | str = False
 
     def __init__(self, root: str, annFile: str, *, auto_fix: bool = False, output_dir: str,
-                 transform=None, device_preprocess: bool = False, **kwargs) -> None:
+                 transform=None, device_preprocess: bool = False,
+                 device_decode: bool | str = False, **kwargs) -> None:
         self.coco = CocoImages(root, annFile)
         self.root = root
         self.ids = self.coco.ids
@@ -64,7 +87,11 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
         self._auto_fix = auto_fix
         # True: workers only decode; crop / antialiased-bicubic resize / normalise run on the GPU
         # (csrc/resample.hip, bit-exact with the PIL path) — needs a HIP device in the main process
-        self._device_preprocess = device_preprocess
+        self._device_preprocess = device_preprocess or bool(device_decode)
+        # True: workers only read the file; baseline JPEGs are decoded on the GPU (csrc/jpeg.hip,
+        # bit-identical to PIL); files outside that subset (progressive, CMYK, PNG, ...) take the
+        # reference's own PIL decode in the worker.  'strict': raise for those instead.
+        self._device_decode = device_decode
         self._output_dir = pathlib.Path(output_dir)
         self._output_dir.mkdir(parents=True, exist_ok=True)
 
@@ -78,9 +105,16 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
     def __len__(self) -> int:
         return len(self.ids)
 
-    def _load_image(self, id_: int) -> PIL.Image.Image:
-        path = self.coco.loadImgs([id_])[0]['file_name']
-        return PIL.Image.open(os.path.join(self.root, path)).convert('RGB')
+    def _load_image(self, id_: int) -> PIL.Image.Image | EncodedImage:
+        path = os.path.join(self.root, self.coco.loadImgs([id_])[0]['file_name'])
+        if self._device_decode:
+            data = pathlib.Path(path).read_bytes()
+            size = jpeg_size(data)
+            if size is not None:
+                return EncodedImage(data, size)
+            if self._device_decode == 'strict':
+                raise ValueError(f'{path}: not a baseline JPEG the device decoder supports')
+        return PIL.Image.open(path).convert('RGB')
 
     def __getitem__(self, index: int) -> T | None:
         # reference oadp/oake/base.py:42-54 (resume by skipping; auto_fix re-verifies the file)
@@ -102,9 +136,12 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
         pass
 
 
-def image_to_u8(image: PIL.Image.Image) -> torch.Tensor:
-    """RGB PIL image -> uint8 HWC tensor (what the device preprocessing kernels consume)."""
+def image_to_u8(image: PIL.Image.Image | EncodedImage) -> torch.Tensor:
+    """RGB PIL image -> uint8 HWC tensor (what the device preprocessing kernels consume); an
+    ``EncodedImage`` -> its file bytes as a 1-D uint8 tensor (decoded by ``BaseValidator._image_u8``)."""
     import numpy as np
+    if isinstance(image, EncodedImage):
+        return torch.frombuffer(bytearray(image.data), dtype=torch.uint8)
     return torch.from_numpy(np.asarray(image.convert('RGB'), dtype=np.uint8).copy())
 
 
@@ -254,6 +291,12 @@ class BaseValidator(ABC, Generic[T]):
 
     def _n_crops(self, batch: T) -> int:
         return 1
+
+    def _image_u8(self, t: torch.Tensor) -> torch.Tensor:
+        """What ``image_to_u8`` produced -> uint8 HWC image on the device (JPEG bytes are decoded there)."""
+        if t.dim() == 1:
+            return self._model.visual.decode_jpeg(t.numpy().tobytes(), self._device)
+        return t.to(self._device, non_blocking=True)
 
     def _flush(self, pending: list[T]) -> None:
         if not pending:

@@ -113,7 +113,7 @@ class Validator(BaseValidator[Batch]):
         exact 224x224 crops of the level image, levels chained by Pillow-exact resizes."""
         ds = self._dataloader.dataset
         v = self._model.visual
-        level = image_u8.to(self._device, non_blocking=True)
+        level = self._image_u8(image_u8)
         h, w = level.shape[:2]
         out = [v.crop_resize_normalize(level, [(0, 0, w, h)], out_dtype=torch.float16)]
         r = ds._r

@@ -46,10 +46,10 @@ class Validator(BaseValidator[Batch]):
             squash = getattr(self._dataloader.dataset.transform, 'squash', False)
             crops = []
             for b in batches:
-                h, w = b.image.shape[:2]
+                image = self._image_u8(b.image)
+                h, w = image.shape[:2]
                 crops.append(self._model.visual.crop_resize_normalize(
-                    b.image.to(self._device, non_blocking=True), [(0, 0, w, h)], squash=squash,
-                    out_dtype=torch.float16))
+                    image, [(0, 0, w, h)], squash=squash, out_dtype=torch.float16))
             images = torch.cat(crops)
         else:
             images = torch.stack([b.image for b in batches]).to(self._device, non_blocking=True)

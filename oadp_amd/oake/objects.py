@@ -176,7 +176,7 @@ class Validator(BaseValidator[Batch]):
             # device preprocessing: preprocess(image.crop(box)) for all proposals of an image in
             # three kernel launches, bit-exact with the PIL path
             objects = torch.cat([self._model.visual.crop_resize_normalize(
-                b.objects.to(self._device, non_blocking=True), b.crop_boxes, out_dtype=torch.float16)
+                self._image_u8(b.objects), b.crop_boxes, out_dtype=torch.float16)
                 for b in batches])
         else:
             objects = torch.cat([b.objects for b in batches])

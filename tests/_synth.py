@@ -14,7 +14,7 @@ from oracle.vit_ref import ViTConfig, encode_image_ref, encode_objects_ref
 TINY = dict(width=128, layers=1, heads=2, mlp_dim=256, embed_dim=64)
 
 
-def make_coco(root: pathlib.Path, sizes, proposals_per_image: int = 12, seed: int = 0):
+def make_coco(root: pathlib.Path, sizes, proposals_per_image: int = 12, seed: int = 0, fmt: str = 'png'):
     """Writes <root>/images/*.jpg-like PNGs, an instances json (shuffled id order) and a proposals pkl
     aligned with SORTED ids (proposal_sorted=True)."""
     img_dir = root / 'images'
@@ -24,8 +24,18 @@ def make_coco(root: pathlib.Path, sizes, proposals_per_image: int = 12, seed: in
     ids = [int(i) for i in rng.permutation(np.arange(100, 100 + 7 * len(sizes), 7))[:len(sizes)]]
     for id_, (w, h) in zip(ids, sizes):
         arr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
-        name = f'{id_:012d}.png'
-        PIL.Image.fromarray(arr).save(img_dir / name)
+        name = f'{id_:012d}.{fmt}'
+        if fmt == 'jpg':
+            # smooth content + varied JPEG flavours (4:2:0 / 4:2:2 / 4:4:4, optimised tables, restarts, one
+            # progressive file that the device decoder must hand back to PIL)
+            yy, xx = np.mgrid[0:h, 0:w]
+            arr = (arr // 4 + np.stack([(xx * 3 + yy) % 192, (xx + yy * 2) % 192, (xx * yy) % 192], -1)).astype(np.uint8)
+            k = len(images)
+            PIL.Image.fromarray(arr).save(img_dir / name, quality=(95, 80, 60)[k % 3], subsampling=(2, 1, 0)[k % 3],
+                                          optimize=k % 2 == 1, progressive=k == 2,
+                                          **(dict(restart_marker_blocks=7) if k == 3 else {}))
+        else:
+            PIL.Image.fromarray(arr).save(img_dir / name)
         images.append(dict(id=id_, file_name=name, width=w, height=h,
                            coco_url=f'http://images.cocodataset.org/images/{name}'))
     ann = root / 'instances.json'

@@ -120,6 +120,39 @@ def test_device_preprocess_matches_host_preprocess(cuda, tmp_path, monkeypatch):
                 assert torch.equal(a, b), (tag, id_)
 
 
+def test_device_decode_matches_host_decode(cuda, tmp_path, monkeypatch):
+    """device_decode=True (workers read file bytes; baseline JPEGs decoded by csrc/jpeg.hip, the rest by
+    PIL) writes the same .pth payloads, bit for bit, as PIL decode + host preprocessing."""
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    coco = _synth.make_coco(tmp_path / 'coco', SIZES + [(1000, 700)], fmt='jpg')
+    sd = synthetic_state_dict(**_synth.TINY)
+
+    def run(cls, tag, dev, dataset=None, validator=None):
+        out = tmp_path / f'{tag}_{int(dev)}'
+        model, pre = clip.load(sd, max_batch=64)
+        dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(out),
+                                 transform=pre, device_decode=dev, **(dataset or {})), num_workers=0)
+        cls(tag, model, dataloader=dl, device='cuda:0', **(validator or {})).run()
+        return out
+
+    for cls, tag, kw in [(globals_.Validator, 'g', {}),
+                         (blocks.Validator, 'b', dict(validator=dict(batch_size=64)))]:
+        host, dev = run(cls, tag, False, **kw), run(cls, tag, True, **kw)
+        for id_ in coco['ids']:
+            a, b = torch.load(host / f'{id_:012d}.pth', 'cpu'), torch.load(dev / f'{id_:012d}.pth', 'cpu')
+            if isinstance(a, dict):
+                for k in a:
+                    assert torch.equal(a[k], b[k]), (tag, id_, k)
+            else:
+                assert torch.equal(a, b), (tag, id_)
+    # 'strict' refuses the progressive file instead of handing it to PIL
+    with pytest.raises(ValueError):
+        model, pre = clip.load(sd, max_batch=64)
+        dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 's'),
+                                 transform=pre, device_decode='strict'), num_workers=0)
+        globals_.Validator('s', model, dataloader=dl, device='cuda:0').run()
+
+
 def test_crop_normalize_kernel_is_bit_exact(cuda, lib):
     """GPU crop + ToTensor + Normalize of level-0 blocks == the host transform, bit for bit."""
     from oadp_amd.clip.preprocess import CLIP_MEAN, CLIP_STD

@@ -7,6 +7,7 @@ import pathlib
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -188,3 +189,32 @@ def test_async_writer_contract(tmp_path, threads):
         w.submit(payloads[0], tmp_path / 'no_such_dir' / 'x.pth')
         w.drain()
     w.close()
+
+
+def test_device_decode_dataset_hands_over_file_bytes(tmp_path):
+    """device_decode=True: baseline JPEGs travel as file bytes (1-D uint8) with the size taken from the
+    header by oake_jpeg_info (host only); files the device decoder does not cover are decoded by PIL
+    in the worker (uint8 HWC) — or refused with 'strict'."""
+    from oadp_amd.oake import globals as globals_
+    from tests import _synth
+    coco = _synth.make_coco(tmp_path / 'coco', [(64, 48), (50, 70), (33, 40), (90, 30)], fmt='jpg')
+    ds = globals_.Dataset(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 'o'),
+                          transform=_synth.preprocess(), device_decode=True)
+    kinds = []
+    for i in range(len(ds)):
+        b = ds[i]
+        name = ds.coco.loadImgs([ds.ids[i]])[0]['file_name']
+        raw = (tmp_path / 'coco' / 'images' / name).read_bytes()
+        if b.image.dim() == 1:
+            assert bytes(b.image.numpy().tobytes()) == raw
+            kinds.append('bytes')
+        else:
+            import PIL.Image
+            assert b.image.dtype == torch.uint8 and b.image.shape[2] == 3
+            assert np.array_equal(b.image.numpy(), np.asarray(PIL.Image.open(tmp_path / 'coco' / 'images' / name).convert('RGB')))
+            kinds.append('pixels')
+    assert kinds.count('pixels') == 1 and kinds.count('bytes') == 3  # one progressive file in the set
+    strict = globals_.Dataset(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 'o2'),
+                              transform=_synth.preprocess(), device_decode='strict')
+    with pytest.raises(ValueError):
+        [strict[i] for i in range(len(strict))]
