@@ -190,10 +190,17 @@ OAKE_API int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, in
 OAKE_API int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width, int* components);
 OAKE_API int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8_t* d_out_hwc,
                      size_t out_capacity, int* height, int* width, void* stream);
-/* Host half only (tests; no handle, no GPU): the quantised DCT coefficients of every component,
- * [component][block row][block column][64] in natural order, MCU-padded.  h_coefs NULL: size query. */
-OAKE_API int oake_debug_jpeg_coefs(const uint8_t* h_data, size_t nbytes, int16_t* h_coefs, size_t capacity,
-                          size_t* total);
+/* The two halves separately, so that the serial half can run in many worker processes:
+ * oake_jpeg_entropy_decode — host only, no handle, no GPU: the quantised DCT coefficients of every
+ *   component, [component][block row][block column][64] in natural order, MCU-padded (h_coefs NULL:
+ *   size query through *total);
+ * oake_jpeg_reconstruct — uploads such coefficients (h_data is needed again for the frame header and
+ *   quantisation tables) and runs IDCT / upsampling / colour conversion on `stream`. */
+OAKE_API int oake_jpeg_entropy_decode(const uint8_t* h_data, size_t nbytes, int16_t* h_coefs, size_t capacity,
+                             size_t* total);
+OAKE_API int oake_jpeg_reconstruct(oake_handle* h, const uint8_t* h_data, size_t nbytes, const int16_t* h_coefs,
+                          size_t ncoefs, uint8_t* d_out_hwc, size_t out_capacity, int* height,
+                          int* width, void* stream);
 
 /*
  * Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).

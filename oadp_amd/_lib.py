@@ -46,7 +46,8 @@ SIGNATURES = {
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), _VP, _I, _VP]),
     'oake_resize_u8': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     'oake_jpeg_info': (_I, [_VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    'oake_debug_jpeg_coefs': (_I, [_VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    'oake_jpeg_entropy_decode': (_I, [_VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    'oake_jpeg_reconstruct': (_I, [_VP, _VP, C.c_size_t, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
     'oake_decode_jpeg': (_I, [_VP, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
     'oake_profile_enable': (_I, [_VP, _I]),
     'oake_profile_read': (_I, [_VP, C.POINTER(ProfileEntry), _I, C.POINTER(_I)]),

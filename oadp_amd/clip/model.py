@@ -246,10 +246,13 @@ class VisionTransformer:
             _lib.check(self._lib, h, rc, 'oake_resize_u8')
         return out
 
-    def decode_jpeg(self, data: bytes, device: torch.device | None = None) -> torch.Tensor:
+    def decode_jpeg(self, data: bytes, device: torch.device | None = None, *,
+                    coefs: torch.Tensor | None = None) -> torch.Tensor:
         """Baseline JPEG file bytes -> uint8 HWC RGB device tensor, bit-identical to
         ``PIL.Image.open(...).convert('RGB')`` (the decode behind oadp/oake/base.py:53).  Huffman
         decoding runs on the calling thread, IDCT / upsampling / colour conversion on the GPU.
+        ``coefs``: the int16 output of ``oake_jpeg_entropy_decode`` when the Huffman pass already ran
+        elsewhere (a DataLoader worker) — then only the upload + GPU half runs here.
         Raises ``OakeError`` for files outside the supported subset (progressive, CMYK, ...)."""
         dev = torch.device(device).index if device is not None else None
         dev = torch.cuda.current_device() if dev is None else dev
@@ -262,8 +265,16 @@ class VisionTransformer:
         out = torch.empty((hh.value, ww.value, 3), dtype=torch.uint8, device=torch.device('cuda', dev))
         with torch.cuda.device(dev):
             h = self._ensure_handle(dev)
-            rc = self._lib.oake_decode_jpeg(h, buf, len(data), out.data_ptr(), out.numel(), C.byref(hh),
-                                            C.byref(ww), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if coefs is None:
+                rc = self._lib.oake_decode_jpeg(h, buf, len(data), out.data_ptr(), out.numel(), C.byref(hh),
+                                                C.byref(ww), stream)
+            else:
+                if coefs.dtype != torch.int16 or coefs.is_cuda or not coefs.is_contiguous():
+                    raise ValueError('coefs must be a contiguous int16 CPU tensor')
+                rc = self._lib.oake_jpeg_reconstruct(h, buf, len(data), C.c_void_p(coefs.data_ptr()),
+                                                     coefs.numel(), out.data_ptr(), out.numel(),
+                                                     C.byref(hh), C.byref(ww), stream)
             _lib.check(self._lib, h, rc, 'oake_decode_jpeg')
         return out
 

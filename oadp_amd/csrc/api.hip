@@ -850,7 +850,7 @@ int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width
   return OAKE_OK;
 }
 
-int oake_debug_jpeg_coefs(const uint8_t* h_data, size_t nbytes, int16_t* h_coefs, size_t capacity,
+int oake_jpeg_entropy_decode(const uint8_t* h_data, size_t nbytes, int16_t* h_coefs, size_t capacity,
                           size_t* total) {
   if (!h_data) return OAKE_ERR_INVALID;
   JpegFrame f;
@@ -864,22 +864,20 @@ int oake_debug_jpeg_coefs(const uint8_t* h_data, size_t nbytes, int16_t* h_coefs
   return rc == JPEG_OK ? OAKE_OK : (rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID);
 }
 
-int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8_t* d_out_hwc,
-                     size_t out_capacity, int* height, int* width, void* stream) {
-  if (!h) return OAKE_ERR_INVALID;
-  if (!h_data || !d_out_hwc) return fail(h, OAKE_ERR_INVALID, "null pointer");
-  HIP_TRY(h, hipSetDevice(h->device));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  JpegFrame f;
+namespace {
+
+// frame walk + scratch sizing shared by the two decode entry points; leaves jp_host writable
+int jpeg_prepare(oake_handle* h, hipStream_t s, const uint8_t* h_data, size_t nbytes, size_t out_capacity,
+                 JpegFrame* f, int* height, int* width) {
   std::string err;
-  int rc = jpeg_read_frame(h_data, nbytes, &f, &err);
+  int rc = jpeg_read_frame(h_data, nbytes, f, &err);
   if (rc != JPEG_OK)
     return fail(h, rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID, "jpeg: " + err);
-  if (height) *height = f.height;
-  if (width) *width = f.width;
-  if ((size_t)f.height * f.width * 3 > out_capacity)
+  if (height) *height = f->height;
+  if (width) *width = f->width;
+  if ((size_t)f->height * f->width * 3 > out_capacity)
     return fail(h, OAKE_ERR_INVALID, "jpeg: output buffer too small");
-  const size_t cbytes = (size_t)f.total_coefs * sizeof(int16_t);
+  const size_t cbytes = (size_t)f->total_coefs * sizeof(int16_t);
   if (!h->jp_copied) HIP_TRY(h, hipEventCreateWithFlags(&h->jp_copied, hipEventDisableTiming));
   if (cbytes > h->jp_host_cap) {
     HIP_TRY(h, hipEventSynchronize(h->jp_copied));
@@ -891,17 +889,53 @@ int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8
     h->jp_host_cap = cap;
   }
   if ((rc = grow(h, s, &h->jp_coefs, &h->jp_coefs_cap, cbytes))) return rc;
-  if ((rc = grow(h, s, &h->jp_planes, &h->jp_planes_cap, (size_t)f.total_plane_bytes))) return rc;
+  if ((rc = grow(h, s, &h->jp_planes, &h->jp_planes_cap, (size_t)f->total_plane_bytes))) return rc;
   // the previous image's coefficients must have left the pinned buffer before it is rewritten
   HIP_TRY(h, hipEventSynchronize(h->jp_copied));
-  rc = jpeg_decode_coefs(h_data, nbytes, f, h->jp_host, &err);
-  if (rc != JPEG_OK)
-    return fail(h, rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID, "jpeg: " + err);
+  return OAKE_OK;
+}
+
+int jpeg_upload_and_reconstruct(oake_handle* h, hipStream_t s, const JpegFrame& f, uint8_t* d_out_hwc) {
+  const size_t cbytes = (size_t)f.total_coefs * sizeof(int16_t);
   HIP_TRY(h, hipMemcpyAsync(h->jp_coefs, h->jp_host, cbytes, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipEventRecord(h->jp_copied, s));
   RUN(h, s, "jpeg_reconstruct", 0.0, (double)cbytes + 2.0 * f.total_plane_bytes + 3.0 * f.height * f.width,
       launch_jpeg_reconstruct(f, h->jp_coefs, h->jp_planes, d_out_hwc, s));
   return OAKE_OK;
+}
+
+}  // namespace
+
+int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8_t* d_out_hwc,
+                     size_t out_capacity, int* height, int* width, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (!h_data || !d_out_hwc) return fail(h, OAKE_ERR_INVALID, "null pointer");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  JpegFrame f;
+  int rc = jpeg_prepare(h, s, h_data, nbytes, out_capacity, &f, height, width);
+  if (rc) return rc;
+  std::string err;
+  rc = jpeg_decode_coefs(h_data, nbytes, f, h->jp_host, &err);
+  if (rc != JPEG_OK)
+    return fail(h, rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID, "jpeg: " + err);
+  return jpeg_upload_and_reconstruct(h, s, f, d_out_hwc);
+}
+
+int oake_jpeg_reconstruct(oake_handle* h, const uint8_t* h_data, size_t nbytes, const int16_t* h_coefs,
+                          size_t ncoefs, uint8_t* d_out_hwc, size_t out_capacity, int* height,
+                          int* width, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (!h_data || !h_coefs || !d_out_hwc) return fail(h, OAKE_ERR_INVALID, "null pointer");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  JpegFrame f;
+  int rc = jpeg_prepare(h, s, h_data, nbytes, out_capacity, &f, height, width);
+  if (rc) return rc;
+  if (ncoefs != (size_t)f.total_coefs)
+    return fail(h, OAKE_ERR_INVALID, "jpeg: coefficient count does not match the frame header");
+  std::memcpy(h->jp_host, h_coefs, ncoefs * sizeof(int16_t));
+  return jpeg_upload_and_reconstruct(h, s, f, d_out_hwc);
 }
 
 int oake_profile_enable(oake_handle* h, int enable) {

@@ -53,15 +53,33 @@ class CocoImages:
 
 
 class EncodedImage:
-    """Stands in for the PIL image on the device-decode path: the host only knows the size."""
+    """Stands in for the PIL image on the device-decode path: the host knows the size and holds the
+    file bytes plus the entropy-decoded DCT coefficients (the serial half of JPEG decoding, done here
+    in the DataLoader worker); IDCT / upsampling / colour conversion happen on the GPU."""
 
-    def __init__(self, data: bytes, size: tuple[int, int]) -> None:
+    def __init__(self, data: bytes, size: tuple[int, int], coefs: torch.Tensor) -> None:
         self.data = data
         self.size = size  # (width, height), as PIL.Image.size
+        self.coefs = coefs  # int16, layout of oake_jpeg_entropy_decode
+
+    def packed(self) -> torch.Tensor:
+        """One 1-D uint8 tensor for the Batch: [nbytes: int64][file bytes][pad to 8][coefficients]."""
+        n = len(self.data)
+        pad = -n % 8
+        head = torch.tensor([n], dtype=torch.int64).view(torch.uint8)
+        body = torch.frombuffer(bytearray(self.data + bytes(pad)), dtype=torch.uint8)
+        return torch.cat([head, body, self.coefs.view(torch.uint8)])
+
+    @staticmethod
+    def unpack(t: torch.Tensor) -> tuple[bytes, torch.Tensor]:
+        n = int(t[:8].view(torch.int64)[0])
+        start = 8 + n + (-n % 8)
+        return t[8:8 + n].numpy().tobytes(), t[start:].view(torch.int16)
 
 
-def jpeg_size(data: bytes) -> tuple[int, int] | None:
-    """(width, height) if ``oake_decode_jpeg`` can decode this file, else None (no GPU involved)."""
+def jpeg_entropy_decode(data: bytes) -> EncodedImage | None:
+    """Header walk + Huffman pass of liboake_hip.so (host only, no GPU): an ``EncodedImage`` if
+    ``oake_jpeg_reconstruct`` can finish this file on the device, else None."""
     import ctypes as C
 
     from .. import _lib
@@ -70,7 +88,14 @@ def jpeg_size(data: bytes) -> tuple[int, int] | None:
     h, w = C.c_int(0), C.c_int(0)
     if lib.oake_jpeg_info(buf, len(data), C.byref(h), C.byref(w), None) != _lib.OAKE_OK:
         return None
-    return w.value, h.value
+    total = C.c_size_t(0)
+    if lib.oake_jpeg_entropy_decode(buf, len(data), None, 0, C.byref(total)) != _lib.OAKE_OK:
+        return None
+    coefs = torch.empty(total.value, dtype=torch.int16)
+    if lib.oake_jpeg_entropy_decode(buf, len(data), C.c_void_p(coefs.data_ptr()), total.value,
+                                    C.byref(total)) != _lib.OAKE_OK:
+        return None  # corrupt entropy segment: let PIL have the final word on this file
+    return EncodedImage(data, (w.value, h.value), coefs)
 
 
 class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
@@ -88,9 +113,10 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
         # True: workers only decode; crop / antialiased-bicubic resize / normalise run on the GPU
         # (csrc/resample.hip, bit-exact with the PIL path) — needs a HIP device in the main process
         self._device_preprocess = device_preprocess or bool(device_decode)
-        # True: workers only read the file; baseline JPEGs are decoded on the GPU (csrc/jpeg.hip,
-        # bit-identical to PIL); files outside that subset (progressive, CMYK, PNG, ...) take the
-        # reference's own PIL decode in the worker.  'strict': raise for those instead.
+        # True: for baseline JPEGs the workers run only the Huffman pass; IDCT / upsampling / colour
+        # conversion run on the GPU (csrc/jpeg.hip, bit-identical to PIL); files outside that subset
+        # (progressive, CMYK, PNG, ...) take the reference's own PIL decode in the worker.
+        # 'strict': raise for those instead.
         self._device_decode = device_decode
         self._output_dir = pathlib.Path(output_dir)
         self._output_dir.mkdir(parents=True, exist_ok=True)
@@ -108,10 +134,9 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
     def _load_image(self, id_: int) -> PIL.Image.Image | EncodedImage:
         path = os.path.join(self.root, self.coco.loadImgs([id_])[0]['file_name'])
         if self._device_decode:
-            data = pathlib.Path(path).read_bytes()
-            size = jpeg_size(data)
-            if size is not None:
-                return EncodedImage(data, size)
+            enc = jpeg_entropy_decode(pathlib.Path(path).read_bytes())
+            if enc is not None:
+                return enc
             if self._device_decode == 'strict':
                 raise ValueError(f'{path}: not a baseline JPEG the device decoder supports')
         return PIL.Image.open(path).convert('RGB')
@@ -141,7 +166,7 @@ def image_to_u8(image: PIL.Image.Image | EncodedImage) -> torch.Tensor:
     ``EncodedImage`` -> its file bytes as a 1-D uint8 tensor (decoded by ``BaseValidator._image_u8``)."""
     import numpy as np
     if isinstance(image, EncodedImage):
-        return torch.frombuffer(bytearray(image.data), dtype=torch.uint8)
+        return image.packed()
     return torch.from_numpy(np.asarray(image.convert('RGB'), dtype=np.uint8).copy())
 
 
@@ -295,7 +320,8 @@ class BaseValidator(ABC, Generic[T]):
     def _image_u8(self, t: torch.Tensor) -> torch.Tensor:
         """What ``image_to_u8`` produced -> uint8 HWC image on the device (JPEG bytes are decoded there)."""
         if t.dim() == 1:
-            return self._model.visual.decode_jpeg(t.numpy().tobytes(), self._device)
+            data, coefs = EncodedImage.unpack(t)
+            return self._model.visual.decode_jpeg(data, self._device, coefs=coefs)
         return t.to(self._device, non_blocking=True)
 
     def _flush(self, pending: list[T]) -> None:

@@ -62,10 +62,10 @@ def test_oracle_rejects_progressive():
 def _host_coefs(lib, data):
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     total = C.c_size_t(0)
-    rc = lib.oake_debug_jpeg_coefs(buf, len(data), None, 0, C.byref(total))
+    rc = lib.oake_jpeg_entropy_decode(buf, len(data), None, 0, C.byref(total))
     assert rc == 0
     out = np.zeros(total.value, np.int16)
-    rc = lib.oake_debug_jpeg_coefs(buf, len(data), out.ctypes.data_as(C.c_void_p), out.size, C.byref(total))
+    rc = lib.oake_jpeg_entropy_decode(buf, len(data), out.ctypes.data_as(C.c_void_p), out.size, C.byref(total))
     assert rc == 0
     return out
 
@@ -120,6 +120,10 @@ def test_device_decode_matches_pillow(cuda, h, w, ss, q, kind):
     out = model.visual.decode_jpeg(data)
     assert out.dtype == torch.uint8 and out.shape == (h, w, 3) and out.is_cuda
     assert np.array_equal(out.cpu().numpy(), _pil(data))
+    # the two halves separately (Huffman pass in a worker, reconstruction here)
+    from oadp_amd import _lib
+    coefs = torch.from_numpy(_host_coefs(_lib.load(), data))
+    assert torch.equal(model.visual.decode_jpeg(data, coefs=coefs), out)
 
 
 @pytest.mark.gpu

@@ -20,9 +20,9 @@ for (h, w, q) in [(480, 640, 85), (427, 640, 75), (1134, 1700, 90)]:
     for _ in range(n): np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
     t_pil = (time.perf_counter() - t0) / n
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data); total = C.c_size_t(0)
-    lib.oake_debug_jpeg_coefs(buf, len(data), None, 0, C.byref(total)); co = np.zeros(total.value, np.int16)
+    lib.oake_jpeg_entropy_decode(buf, len(data), None, 0, C.byref(total)); co = np.zeros(total.value, np.int16)
     t0 = time.perf_counter()
-    for _ in range(n): lib.oake_debug_jpeg_coefs(buf, len(data), co.ctypes.data_as(C.c_void_p), co.size, C.byref(total))
+    for _ in range(n): lib.oake_jpeg_entropy_decode(buf, len(data), co.ctypes.data_as(C.c_void_p), co.size, C.byref(total))
     t_huff = (time.perf_counter() - t0) / n
     out = model.visual.decode_jpeg(data); torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), np.asarray(Image.open(io.BytesIO(data)).convert('RGB')))
