@@ -28,9 +28,14 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
                              58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+constexpr int kLook = 10;  // look-ahead bits
+
 struct Huff {
-  // jdhuff.c derived table: codes of <= 9 bits resolve in one lookup, longer ones by length
-  uint16_t look[512];  // (length << 8) | symbol, 0 = code longer than 9 bits
+  // jdhuff.c derived table: codes of <= kLook bits resolve in one lookup, longer ones by length
+  uint16_t look[1 << kLook];  // (length << 8) | symbol, 0 = code longer than kLook bits
+  // AC shortcut: when code + magnitude bits fit the look-ahead, one lookup yields everything:
+  // (coefficient << 16) | (run << 8) | total bits consumed; 0 = take the slow path
+  int32_t fast_ac[1 << kLook];
   int32_t maxcode[18];
   int32_t valoff[17];
   uint8_t vals[256];
@@ -38,20 +43,30 @@ struct Huff {
 
   void build(const uint8_t* bits, const uint8_t* v, int n) {
     memset(look, 0, sizeof(look));
+    memset(fast_ac, 0, sizeof(fast_ac));
     memcpy(vals, v, n);
     int code = 0, k = 0;
     for (int len = 1; len <= 16; ++len) {
       valoff[len] = k - code;
       for (int i = 0; i < bits[len - 1]; ++i, ++k, ++code) {
-        if (len <= 9) {
-          const int base = code << (9 - len);
-          for (int f = 0; f < (1 << (9 - len)); ++f) look[base + f] = (uint16_t)((len << 8) | v[k]);
+        if (len <= kLook) {
+          const int base = code << (kLook - len);
+          for (int f = 0; f < (1 << (kLook - len)); ++f) look[base + f] = (uint16_t)((len << 8) | v[k]);
         }
       }
       maxcode[len] = bits[len - 1] ? code - 1 : -1;
       code <<= 1;
     }
     maxcode[17] = 0x7fffffff;
+    for (int w = 0; w < (1 << kLook); ++w) {
+      const int e = look[w];
+      if (!e) continue;
+      const int len = e >> 8, rs = e & 0xFF, run = rs >> 4, mag = rs & 15;
+      if (mag == 0 || len + mag > kLook) continue;
+      int val = (w >> (kLook - len - mag)) & ((1 << mag) - 1);
+      if (val < (1 << (mag - 1))) val += 1 - (1 << mag);
+      fast_ac[w] = (int32_t)((uint32_t)val << 16) | (run << 8) | (len + mag);
+    }
     present = true;
   }
 };
@@ -88,13 +103,13 @@ struct BitReader {
   inline void drop(int k) { cnt -= k; }
   inline int decode(const Huff& t) {
     if (cnt < 16) fill();
-    const uint16_t e = t.look[peek(9)];
+    const uint16_t e = t.look[peek(kLook)];
     if (e) {
       drop(e >> 8);
       return e & 0xFF;
     }
-    int len = 10;
-    int32_t code = (int32_t)peek(10);
+    int len = kLook + 1;
+    int32_t code = (int32_t)peek(kLook + 1);
     while (len <= 16 && code > t.maxcode[len]) {
       ++len;
       code = (int32_t)peek(len);
@@ -294,6 +309,19 @@ int jpeg_decode_coefs(const uint8_t* data, size_t n, const JpegFrame& fr, int16_
             if (s) pred[c] += br.receive_extend(s);
             blk[0] = (int16_t)pred[c];
             for (int k = 1; k < 64;) {
+              if (br.cnt < 32) br.fill();
+              const int32_t fa = ha.fast_ac[br.peek(kLook)];
+              if (fa) {  // run, magnitude bits and value in one lookup
+                k += (fa >> 8) & 15;
+                if (k > 63) {
+                  if (err) *err = "AC run past the block";
+                  return JPEG_INVALID;
+                }
+                br.drop(fa & 255);
+                blk[kZigzag[k]] = (int16_t)(fa >> 16);
+                ++k;
+                continue;
+              }
               const int rs = br.decode(ha);
               if (rs < 0) {
                 if (err) *err = "corrupt AC code";
