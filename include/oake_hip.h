@@ -179,6 +179,24 @@ OAKE_API int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, in
                    uint8_t* d_dst_hwc, int dh, int dw, void* stream);
 
 /*
+ * Text tower: model.encode_text(tokens) of oadp/prompts/vild.py:62-66 — the
+ * same transformer blocks with a causal attention mask.  Tensor names as in the CLIP state dict:
+ * token_embedding.weight [vocab,width], positional_embedding [context,width],
+ * transformer.resblocks.<l>.*, ln_final.{weight,bias}, text_projection [width,embed].
+ * oake_encode_text: d_tokens int32 [n, length] (length <= context: the fork's adaptively_tokenize
+ * trims the context, which a causal model allows); the feature is taken at the position of the
+ * highest token id of each row (the EOT token), as text.argmax(dim=-1) does.
+ */
+typedef struct oake_text_config {
+  int32_t context, vocab, width, layers, heads, mlp_dim, embed_dim, compute_dtype, max_batch;
+  int32_t reserved[3];
+} oake_text_config;
+OAKE_API void oake_text_default_config(oake_text_config* cfg); /* CLIP ViT-B/32 text: 77, 49408, 512, 12, 8, 2048, 512 */
+OAKE_API int oake_text_create(const oake_text_config* cfg, int device, oake_handle** out);
+OAKE_API int oake_encode_text(oake_handle* h, const int32_t* d_tokens, int n, int length, void* d_out,
+                     int out_dtype, int normalize, void* stream);
+
+/*
  * Baseline JPEG -> uint8 HWC RGB on the device, bit-identical to
  * PIL.Image.open(...).convert('RGB') (libjpeg-turbo defaults: islow IDCT, fancy upsampling) — the
  * decode of torchvision CocoDetection._load_image behind oadp/oake/base.py:53.  The Huffman pass runs

@@ -45,6 +45,9 @@ SIGNATURES = {
     'oake_crop_resize_normalize': (_I, [_VP, _VP, _I, _I, C.POINTER(C.c_float), _I, _I, _I,
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), _VP, _I, _VP]),
     'oake_resize_u8': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
+    'oake_text_default_config': (None, [_VP]),
+    'oake_text_create': (_I, [_VP, _I, C.POINTER(C.c_void_p)]),
+    'oake_encode_text': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     'oake_jpeg_info': (_I, [_VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'oake_jpeg_entropy_decode': (_I, [_VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_size_t)]),
     'oake_jpeg_reconstruct': (_I, [_VP, _VP, C.c_size_t, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
@@ -65,6 +68,11 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+class OakeTextConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('context', 'vocab', 'width', 'layers', 'heads', 'mlp_dim',
+                                         'embed_dim', 'compute_dtype', 'max_batch', 'r0', 'r1', 'r2')]
 
 
 def load() -> C.CDLL:

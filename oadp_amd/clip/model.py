@@ -314,15 +314,103 @@ class VisionTransformer:
                      bytes=buf[i].bytes, launches=buf[i].launches) for i in range(min(n.value, 64))]
 
 
+class TextTransformer:
+    """``clip.model.CLIP``'s text tower behind ``oake_encode_text`` (oadp/prompts/vild.py:62-66)."""
+
+    NAMES = ('token_embedding.weight', 'positional_embedding', 'ln_final.weight', 'ln_final.bias',
+             'text_projection')
+
+    def __init__(self, state_dict: Mapping[str, torch.Tensor], *, compute_dtype=torch.float16,
+                 max_batch: int = 256, **_ignored) -> None:
+        self._sd = {k: v.detach().to('cpu', torch.float32).contiguous() for k, v in state_dict.items()
+                    if k in self.NAMES or k.startswith('transformer.resblocks.')}
+        sd = self._sd
+        self.vocab, self.width = sd['token_embedding.weight'].shape
+        self.context = sd['positional_embedding'].shape[0]
+        self.layers = len({k.split('.')[2] for k in sd if k.startswith('transformer.resblocks.')})
+        self.heads = self.width // 64
+        self.mlp_dim = sd['transformer.resblocks.0.mlp.c_fc.weight'].shape[0]
+        self.output_dim = sd['text_projection'].shape[1]
+        self.compute_dtype = compute_dtype
+        self.max_batch = max_batch
+        self._lib = _lib.load()
+        self._handle = None
+        self._handle_dev = None
+
+    def _ensure_handle(self, device_index: int):
+        if self._handle is not None and self._handle_dev == device_index:
+            return self._handle
+        self.close()
+        lib = self._lib
+        cfg = _lib.OakeTextConfig()
+        lib.oake_text_default_config(C.byref(cfg))
+        cfg.context, cfg.vocab, cfg.width, cfg.layers = self.context, self.vocab, self.width, self.layers
+        cfg.heads, cfg.mlp_dim, cfg.embed_dim = self.heads, self.mlp_dim, self.output_dim
+        cfg.compute_dtype = _TORCH2OAKE[self.compute_dtype]
+        cfg.max_batch = self.max_batch
+        h = C.c_void_p()
+        _lib.check(lib, None, lib.oake_text_create(C.byref(cfg), device_index, C.byref(h)), 'oake_text_create')
+        try:
+            for name, t in self._sd.items():
+                _lib.check(lib, h, lib.oake_load_tensor(h, name.encode(), t.data_ptr(), t.numel()),
+                           f'oake_load_tensor({name})')
+            missing = lib.oake_missing_tensors(h)
+            if missing:
+                raise ValueError(f'state_dict lacks {missing} text-tower tensors')
+        except Exception:
+            lib.oake_destroy(h)
+            raise
+        self._handle, self._handle_dev = h, device_index
+        return h
+
+    def close(self) -> None:
+        if self._handle is not None:
+            self._lib.oake_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, tokens: torch.Tensor, *, normalize: bool = False,
+                 out_dtype: torch.dtype | None = None) -> torch.Tensor:
+        if not tokens.is_cuda:
+            raise RuntimeError('oadp_amd.clip runs on the GPU only (no CPU fallback)')
+        if tokens.dim() != 2 or not 1 <= tokens.shape[1] <= self.context:
+            raise ValueError(f'expected [N, L <= {self.context}] token ids, got {tuple(tokens.shape)}')
+        tokens = tokens.to(torch.int32).contiguous()
+        out_dtype = out_dtype or self.compute_dtype
+        dev = tokens.device.index if tokens.device.index is not None else torch.cuda.current_device()
+        out32 = out_dtype != torch.float16
+        out = torch.empty((tokens.shape[0], self.output_dim), device=tokens.device,
+                          dtype=torch.float32 if out32 else torch.float16)
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            rc = self._lib.oake_encode_text(h, tokens.data_ptr(), tokens.shape[0], tokens.shape[1],
+                                            out.data_ptr(), _lib.OAKE_F32 if out32 else _lib.OAKE_F16,
+                                            int(normalize), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_encode_text')
+        return out.to(out_dtype)
+
+
 class CLIP:
-    """The vision half of ``clip.model.CLIP`` (OAKE never calls the text tower)."""
+    """``clip.model.CLIP`` as the reference uses it: ``visual`` / ``encode_image`` for OAKE, and
+    ``encode_text`` (oadp/prompts/vild.py) when the state dict carries the text tower."""
 
     def __init__(self, state_dict: Mapping[str, torch.Tensor], **kwargs) -> None:
-        self.visual = VisionTransformer(state_dict, **kwargs)
+        self.visual = VisionTransformer(state_dict, **kwargs) if 'visual.conv1.weight' in state_dict else None
+        self.text = TextTransformer(state_dict, **kwargs) if 'token_embedding.weight' in state_dict else None
+
+    def encode_text(self, text: torch.Tensor, **kwargs) -> torch.Tensor:
+        if self.text is None:
+            raise RuntimeError('this checkpoint has no text tower')
+        return self.text(text, **kwargs)
 
     @property
     def dtype(self) -> torch.dtype:
-        return self.visual.compute_dtype
+        return (self.visual or self.text).compute_dtype
 
     def encode_image(self, image: torch.Tensor, **kwargs) -> torch.Tensor:
         # reference: self.visual(image.type(self.dtype)); the cast happens inside the im2col kernel
@@ -352,7 +440,7 @@ def load(state_dict: Mapping[str, torch.Tensor] | str | os.PathLike, *, squash: 
     if not isinstance(state_dict, Mapping):
         state_dict = _read_checkpoint(state_dict)
     model = CLIP(state_dict, **kwargs)
-    return model, Preprocess(model.visual.input_resolution, squash=squash)
+    return model, Preprocess(model.visual.input_resolution if model.visual else 224, squash=squash)
 
 
 def load_default(flag: bool = False, **kwargs) -> tuple[CLIP, Preprocess]:

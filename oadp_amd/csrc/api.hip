@@ -66,6 +66,10 @@ struct oake_handle {
   oake_config cfg{};
   int device = 0;
   int grid = 0, tokens = 0, p2 = 0, kpatch = 0;
+  int cur_len = 0;            // tokens per sequence of the pass in flight (text: <= tokens)
+  bool text = false;          // text tower (oake_text_create): causal attention, token embedding
+  int vocab = 0;
+  float* tok_emb = nullptr;   // [vocab, width] fp32 (text)
   int dt16 = DT_F16;
   int xdt = DT_F32;           // residual-stream element type: DT_F32 or dt16
   std::string err;
@@ -205,8 +209,11 @@ const char* kLayerNames[] = {"ln_1.weight",          "ln_1.bias",         "ln_2.
                              "attn.out_proj.weight", "attn.out_proj.bias", "mlp.c_fc.weight",
                              "mlp.c_fc.bias",        "mlp.c_proj.weight", "mlp.c_proj.bias"};
 
-std::string layer_key(int l, const char* leaf) {
-  return "visual.transformer.resblocks." + std::to_string(l) + "." + leaf;
+const char* const kTextGlobalNames[] = {"token_embedding.weight", "positional_embedding", "ln_final.weight",
+                                        "ln_final.bias", "text_projection"};
+
+std::string layer_key(int l, const char* leaf, bool text = false) {
+  return std::string(text ? "" : "visual.") + "transformer.resblocks." + std::to_string(l) + "." + leaf;
 }
 
 int upload_f32(oake_handle* h, float* dst, const float* src, size_t numel) {
@@ -259,7 +266,7 @@ void oake_destroy(oake_handle* h) {
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
                   h->yn, h->qkv_y, h->att_y, h->h_y, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
-                  h->rowstat, h->rowpart, h->jp_coefs, h->jp_planes};
+                  h->rowstat, h->rowpart, h->jp_coefs, h->jp_planes, h->tok_emb};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& l : h->layers) {
@@ -276,24 +283,35 @@ void oake_destroy(oake_handle* h) {
   delete h;
 }
 
-int oake_create(const oake_config* cfg, int device, oake_handle** out) {
+}  // extern "C"
+
+namespace {
+
+// text != 0: cfg.image_size carries the context length, vocab the vocabulary size; no patch embedding
+int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text, int vocab) {
   if (!cfg || !out) {
     g_create_error = "null argument";
     return OAKE_ERR_INVALID;
   }
   *out = nullptr;
-  const oake_config& c = *cfg;
+  oake_config c = *cfg;
   auto bad = [&](const char* m) {
     g_create_error = m;
     return OAKE_ERR_INVALID;
   };
+  if (text) {
+    if (c.image_size <= 0 || vocab <= 0) return bad("context and vocab must be positive");
+    c.patch_size = 8;  // unused; keeps the geometry checks below meaningful for the vision tower only
+    c.stride = 8;
+    c.padding = 0;
+  }
   if (c.width <= 0 || c.heads <= 0 || c.width != c.heads * 64)
     return bad("width must equal heads * 64 (head_dim 64)");
   if (c.width % 64 != 0 || c.mlp_dim % 64 != 0 || c.width > 1024)
     return bad("width/mlp_dim must be multiples of 64 and width <= 1024");
-  if (c.patch_size % 8 != 0 || (3 * c.patch_size * c.patch_size) % 64 != 0)
+  if (!text && (c.patch_size % 8 != 0 || (3 * c.patch_size * c.patch_size) % 64 != 0))
     return bad("patch_size must be a multiple of 8");
-  if (c.stride <= 0 || c.padding < 0 || c.image_size + 2 * c.padding < c.patch_size)
+  if (!text && (c.stride <= 0 || c.padding < 0 || c.image_size + 2 * c.padding < c.patch_size))
     return bad("bad conv1 geometry");
   if (c.embed_dim % 4 != 0 || c.embed_dim > 1024 || c.embed_dim <= 0)
     return bad("embed_dim must be a multiple of 4 and <= 1024");
@@ -313,10 +331,16 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   h->device = device;
   h->dt16 = c.compute_dtype;
   h->xdt = c.residual_dtype == OAKE_F32 ? DT_F32 : c.compute_dtype;
-  h->grid = (c.image_size + 2 * c.padding - c.patch_size) / c.stride + 1;
-  h->p2 = h->grid * h->grid;
-  h->tokens = h->p2 + 1;
-  h->kpatch = 3 * c.patch_size * c.patch_size;
+  h->text = text;
+  h->vocab = vocab;
+  if (text) {
+    h->tokens = c.image_size;  // context length
+  } else {
+    h->grid = (c.image_size + 2 * c.padding - c.patch_size) / c.stride + 1;
+    h->p2 = h->grid * h->grid;
+    h->tokens = h->p2 + 1;
+    h->kpatch = 3 * c.patch_size * c.patch_size;
+  }
   h->layers.resize(c.layers);
 
   const size_t C = c.width, F = c.mlp_dim, E = c.embed_dim, L = h->tokens, B = c.max_batch;
@@ -324,11 +348,15 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   auto A = [&](void** p, size_t bytes) {
     if (rc == OAKE_OK) rc = alloc(h, p, bytes);
   };
-  A(&h->conv_w, C * h->kpatch * e16());
-  A((void**)&h->cls, C * 4);
+  if (text) {
+    A((void**)&h->tok_emb, (size_t)vocab * C * 4);
+  } else {
+    A(&h->conv_w, C * h->kpatch * e16());
+    A((void**)&h->cls, C * 4);
+    A((void**)&h->lnpre_g, C * 4);
+    A((void**)&h->lnpre_b, C * 4);
+  }
   A((void**)&h->pos, L * C * 4);
-  A((void**)&h->lnpre_g, C * 4);
-  A((void**)&h->lnpre_b, C * 4);
   A((void**)&h->lnpost_g, C * 4);
   A((void**)&h->lnpost_b, C * 4);
   A(&h->proj, C * E * e16());
@@ -359,7 +387,7 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
   h->stage_elems = std::max<size_t>(std::max<size_t>(C * h->kpatch, F * C), std::max<size_t>(3 * C * C, L * C));
   A((void**)&h->stage, h->stage_elems * 4);
   // workspace
-  A(&h->a_patch, B * h->p2 * h->kpatch * e16());
+  if (!text) A(&h->a_patch, B * h->p2 * h->kpatch * e16());
   A(&h->x, B * L * C * (h->xdt == DT_F32 ? 4 : 2));
   A(&h->xn, B * L * C * e16());
   A(&h->qkv, B * L * 3 * C * e16());
@@ -378,11 +406,55 @@ int oake_create(const oake_config* cfg, int device, oake_handle** out) {
     oake_destroy(h);
     return rc;
   }
-  for (const char* n : kGlobalNames) h->loaded[n] = false;
+  if (text)
+    for (const char* n : kTextGlobalNames) h->loaded[n] = false;
+  else
+    for (const char* n : kGlobalNames) h->loaded[n] = false;
   for (int l = 0; l < c.layers; ++l)
-    for (const char* n : kLayerNames) h->loaded[layer_key(l, n)] = false;
+    for (const char* n : kLayerNames) h->loaded[layer_key(l, n, text)] = false;
   *out = h;
   return OAKE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oake_create(const oake_config* cfg, int device, oake_handle** out) {
+  return create_impl(cfg, device, out, false, 0);
+}
+
+void oake_text_default_config(oake_text_config* c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->context = 77;
+  c->vocab = 49408;
+  c->width = 512;
+  c->layers = 12;
+  c->heads = 8;
+  c->mlp_dim = 2048;
+  c->embed_dim = 512;
+  c->compute_dtype = OAKE_F16;
+  c->max_batch = 1024;
+}
+
+int oake_text_create(const oake_text_config* tc, int device, oake_handle** out) {
+  if (!tc || !out) {
+    g_create_error = "null argument";
+    return OAKE_ERR_INVALID;
+  }
+  oake_config c;
+  std::memset(&c, 0, sizeof(c));
+  c.image_size = tc->context;
+  c.width = tc->width;
+  c.layers = tc->layers;
+  c.heads = tc->heads;
+  c.mlp_dim = tc->mlp_dim;
+  c.embed_dim = tc->embed_dim;
+  c.compute_dtype = tc->compute_dtype;
+  c.max_batch = tc->max_batch;
+  c.residual_dtype = tc->compute_dtype;
+  return create_impl(&c, device, out, true, tc->vocab);
 }
 
 int oake_missing_tensors(const oake_handle* h) {
@@ -417,7 +489,22 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
     if ((rc = upload_16(h, dst, data, n)) != OAKE_OK) return rc;  \
   } while (0)
 
-  if (key == "visual.conv1.weight") W16(h->conv_w, C * h->kpatch);
+  auto load_proj = [&]() -> int {
+    // state_dict layout is [width, embed] (x @ proj); the GEMM wants W[N = embed][K = width]
+    if ((rc = expect(C * E)) != OAKE_OK) return rc;
+    std::vector<float> t(C * E);
+    for (size_t cc = 0; cc < C; ++cc)
+      for (size_t ee = 0; ee < E; ++ee) t[ee * C + cc] = data[cc * E + ee];
+    return upload_16(h, h->proj, t.data(), C * E);
+  };
+  if (h->text && key == "token_embedding.weight") F32(h->tok_emb, (size_t)h->vocab * C);
+  else if (h->text && key == "positional_embedding") F32(h->pos, L * C);
+  else if (h->text && key == "ln_final.weight") F32(h->lnpost_g, C);
+  else if (h->text && key == "ln_final.bias") F32(h->lnpost_b, C);
+  else if (h->text && key == "text_projection") {
+    if ((rc = load_proj()) != OAKE_OK) return rc;
+  }
+  else if (key == "visual.conv1.weight") W16(h->conv_w, C * h->kpatch);
   else if (key == "visual.class_embedding") F32(h->cls, C);
   else if (key == "visual.positional_embedding") F32(h->pos, L * C);
   else if (key == "visual.ln_pre.weight") F32(h->lnpre_g, C);
@@ -434,7 +521,7 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
   }
   else {
     // visual.transformer.resblocks.<l>.<leaf>
-    const std::string prefix = "visual.transformer.resblocks.";
+    const std::string prefix = h->text ? "transformer.resblocks." : "visual.transformer.resblocks.";
     const size_t dot = key.find('.', prefix.size());
     const int l = std::stoi(key.substr(prefix.size(), dot - prefix.size()));
     const std::string leaf = key.substr(dot + 1);
@@ -511,6 +598,7 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   // 16-bit residual stream + every main-stream GEMM on the persistent kernel: LayerNorm statistics
   // are produced by the kernel that writes x (here: slot 0) and consumed by the next GEMM
   const int T = nb * L;
+  h->cur_len = L;
   h->stat_fused = h->xdt != DT_F32 && C % 64 == 0 && C / 64 <= 16 &&
                   gemm_uses_persistent(T, C, C) && gemm_uses_persistent(T, C, c.mlp_dim) &&
                   gemm_uses_persistent(T, 2 * C, C) && gemm_uses_persistent(T, c.mlp_dim, C);
@@ -544,10 +632,10 @@ int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_
 
 int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   // attention + out_proj + MLP of the main token stream (qkv already computed)
-  const int C = h->cfg.width, F = h->cfg.mlp_dim, L = h->tokens, T = nb * L;
+  const int C = h->cfg.width, F = h->cfg.mlp_dim, L = h->cur_len, T = nb * L;
   const int Lp = ((L + 63) / 64) * 64;
   RUN(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
-      launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, s));
+      launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s));
   int rc;
   if ((rc = gemm(h, s, "gemm_out_proj", h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16, h->att, w.out_w, w.out_b, h->x, T, C, C, C))) return rc;
   if (h->xdt == DT_F32) {
@@ -665,6 +753,7 @@ extern "C" {
 int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n, void* d_out,
                       int out_dtype, int normalize, void* stream) {
   if (!h) return OAKE_ERR_INVALID;
+  if (h->text) return fail(h, OAKE_ERR_STATE, "text handle: use oake_encode_text");
   if (n < 0) return fail(h, OAKE_ERR_INVALID, "negative batch");
   if (n == 0) return OAKE_OK;
   if (!d_images || !d_out) return fail(h, OAKE_ERR_INVALID, "null device pointer");
@@ -697,10 +786,57 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
   return OAKE_OK;
 }
 
+int oake_encode_text(oake_handle* h, const int32_t* d_tokens, int n, int length, void* d_out,
+                     int out_dtype, int normalize, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (!h->text) return fail(h, OAKE_ERR_STATE, "not a text handle (oake_text_create)");
+  if (n < 0) return fail(h, OAKE_ERR_INVALID, "negative batch");
+  if (n == 0) return OAKE_OK;
+  if (!d_tokens || !d_out) return fail(h, OAKE_ERR_INVALID, "null device pointer");
+  if (length <= 0 || length > h->tokens) return fail(h, OAKE_ERR_INVALID, "length must be in 1..context");
+  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  int rc = check_ready(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const oake_config& c = h->cfg;
+  const int C = c.width, L = length;
+  const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
+  // the workspace holds max_batch sequences of the full context; shorter sequences pack more per pass
+  const int per_pass = (int)std::min<long>(((long)c.max_batch * h->tokens) / L, 0x7fffffffL / (3L * C * L));
+  for (int b0 = 0; b0 < n; b0 += per_pass) {
+    const int nb = std::min(per_pass, n - b0);
+    const int T = nb * L;
+    const int32_t* toks = d_tokens + (size_t)b0 * L;
+    char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
+    h->cur_len = L;
+    h->stat_fused = h->xdt != DT_F32 && C % 64 == 0 && C / 64 <= 16 &&
+                    gemm_uses_persistent(T, C, C) && gemm_uses_persistent(T, C, c.mlp_dim) &&
+                    gemm_uses_persistent(T, 3 * C, C) && gemm_uses_persistent(T, c.mlp_dim, C);
+    // clip model.py encode_text: token_embedding(text) + positional_embedding[:L]
+    RUN(h, s, "text_embed", 0.0, (double)T * C * 10,
+        launch_text_embed(toks, h->tok_emb, h->pos, h->x, h->xdt, nb, L, C, h->vocab,
+                          h->stat_fused ? h->rowpart : nullptr, s));
+    h->nparts = 1;
+    for (int l = 0; l < c.layers; ++l) {
+      const LayerW& w = h->layers[l];
+      if ((rc = main_in_proj(h, s, w, T, false))) return rc;
+      if ((rc = main_block_tail(h, s, w, nb))) return rc;  // causal attention (h->text)
+    }
+    // x[arange(n), text.argmax(-1)] -> ln_final -> @ text_projection
+    RUN(h, s, "gather_eot", 0.0, (double)nb * C * 6,
+        launch_gather_eot(toks, h->x, h->xdt, h->y, nb, L, C, s));
+    if ((rc = head(h, s, h->y, DT_F32, (long)C, outp, out_dtype, normalize, nb))) return rc;
+  }
+  return OAKE_OK;
+}
+
 int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, const void* d_masks,
                         int mask_dtype, int n, void* d_out, int out_dtype, int normalize,
                         void* stream) {
   if (!h) return OAKE_ERR_INVALID;
+  if (h->text) return fail(h, OAKE_ERR_STATE, "text handle: use oake_encode_text");
   if (n < 0) return fail(h, OAKE_ERR_INVALID, "negative batch");
   if (n == 0) return OAKE_OK;
   if (!d_objects || !d_masks || !d_out) return fail(h, OAKE_ERR_INVALID, "null device pointer");
@@ -1021,7 +1157,7 @@ int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, con
 
 int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads, int dtype16,
                          void* stream) {
-  return dbg(launch_attention(dtype16, d_qkv, d_out, n, l, heads,
+  return dbg(launch_attention(dtype16, d_qkv, d_out, n, l, heads, 0,
                               reinterpret_cast<hipStream_t>(stream)));
 }
 

@@ -30,7 +30,7 @@ constexpr int kVBytesPerWave = 64 * kVStride * 2;  // 9216
 template <typename T, bool USE_TR, int MT>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int L, int H, int QB,
-                                                        int total_waves) {
+                                                        int total_waves, int causal) {
   typedef typename T16<T>::vec8 vec8;
   __shared__ __attribute__((aligned(16))) char smem[4 * kVBytesPerWave];
 
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         for (int r = 0; r < 4; ++r) {
           const int key = k0 + kt * 16 + 4 * g + r;
           float s = sacc[kt][mt][r];
-          s = key < L ? s : -1e30f;
+          // padded keys; causal (text tower, clip build_attention_mask): keys after the query
+          s = (key < L && (!causal || key <= q0 + mt * 16 + fr)) ? s : -1e30f;
           sacc[kt][mt][r] = s;
           mx = fmaxf(mx, s);
         }
@@ -316,29 +317,30 @@ int g_attention_use_tr = 1;
 int g_attention_q32 = 1;
 
 template <typename T, int MT>
-static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, hipStream_t s) {
+static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, int causal,
+                          hipStream_t s) {
   const int QB = (L + 16 * MT - 1) / (16 * MT);
   const int tw = n * heads * QB;
   const dim3 g((tw + 3) / 4), b(256);
   const T* in = reinterpret_cast<const T*>(qkv);
   T* o = reinterpret_cast<T*>(out);
   if (g_attention_use_tr)
-    hipLaunchKernelGGL((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw);
+    hipLaunchKernelGGL((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
   else
-    hipLaunchKernelGGL((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw);
+    hipLaunchKernelGGL((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
 }
 
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
-                            hipStream_t s) {
+                            int causal, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
   if (dtype16 == DT_F16) {
-    if (g_attention_q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, s);
-    else attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, s);
+    if (g_attention_q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, causal, s);
+    else attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, causal, s);
   } else if (dtype16 == DT_BF16) {
-    if (g_attention_q32) attn_launch_t<bf16_t, 2>(qkv, out, n, L, heads, s);
-    else attn_launch_t<bf16_t, 4>(qkv, out, n, L, heads, s);
+    if (g_attention_q32) attn_launch_t<bf16_t, 2>(qkv, out, n, L, heads, causal, s);
+    else attn_launch_t<bf16_t, 4>(qkv, out, n, L, heads, causal, s);
   } else {
     return hipErrorInvalidValue;
   }

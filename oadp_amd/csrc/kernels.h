@@ -79,14 +79,24 @@ hipError_t launch_rowsums(const void* x, int x_dtype, long x_row_stride, float* 
 // y[n, :] (fp32) = x[n*L + 0, :]  (objects mode: object-token stream starts as the CLS row)
 hipError_t launch_copy_cls(const void* x, int x_dtype, float* y, int n, int L, int c, hipStream_t s);
 
+// ---- text tower glue (oadp/prompts/vild.py -> clip encode_text) ------------------------------
+// x[n*L + t, :] = tok_emb[tokens[n*L + t], :] + pos[t, :]  (residual-stream type);  rowpart as in
+// launch_embed_ln_pre (slot 0 = row sums) or nullptr
+hipError_t launch_text_embed(const int32_t* tokens, const float* tok_emb, const float* pos, void* x,
+                             int x_dtype, int n, int L, int c, int vocab, float* rowpart, hipStream_t s);
+// y[i, :] (fp32) = x[i*L + argmax_t tokens[i*L + t], :]   (the EOT position: highest token id, first hit)
+hipError_t launch_gather_eot(const int32_t* tokens, const void* x, int x_dtype, float* y, int n, int L,
+                             int c, hipStream_t s);
+
 // im2col of NCHW images into the conv1 GEMM A operand [n*G*G, 3*P*P] (16-bit).
 hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, int n, int image,
                          int patch, int stride, int pad, int grid, hipStream_t s);
 
 // ---- attention ---------------------------------------------------------------------------
 // qkv [n*L, 3*H*64] 16-bit (q pre-scaled by 1/8) -> out [n*L, H*64] 16-bit. Full self-attention.
+// causal != 0: key j is visible to query i only if j <= i (text tower)
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
-                            hipStream_t s);
+                            int causal, hipStream_t s);
 
 // Object-token attention (oadp/oake/objects.py:232-247): one query per crop (qkv_y row n),
 // keys/values = patch rows 1..L-1 of qkv_x plus the object token's own k/v (qkv_y);

@@ -258,6 +258,69 @@ __global__ __launch_bounds__(256) void im2col_kernel(const TIN* __restrict__ img
   reinterpret_cast<uint4*>(out)[idx] = o;
 }
 
+// ---- text tower glue --------------------------------------------------------------------------
+// token + positional embedding (clip model.py encode_text: token_embedding(text) + positional_embedding)
+template <typename TX>
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tokens,
+                                                         const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos,
+                                                         TX* __restrict__ x, int rows, int L, int c,
+                                                         int vocab, float2* __restrict__ rowpart) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = c >> 2;
+  int tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  const float4* e4 = reinterpret_cast<const float4*>(tok_emb + (size_t)tok * c);
+  const float4* p4 = reinterpret_cast<const float4*>(pos + (size_t)(row % L) * c);
+  TX* xr = x + (size_t)row * c;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i)
+    if (lane + 64 * i < nv) {
+      const float4 a = e4[lane + 64 * i], b = p4[lane + 64 * i];
+      const float o0 = a.x + b.x, o1 = a.y + b.y, o2 = a.z + b.z, o3 = a.w + b.w;
+      store4<TX>(xr, lane + 64 * i, o0, o1, o2, o3);
+      s1 += (o0 + o1) + (o2 + o3);
+      s2 += (o0 * o0 + o1 * o1) + (o2 * o2 + o3 * o3);
+    }
+  if (rowpart != nullptr) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) rowpart[(size_t)row * 16] = make_float2(s1, s2);
+  }
+}
+
+// one wave per sequence: argmax over the token ids (first maximum, like torch.argmax), then copy that row
+template <typename TX>
+__global__ __launch_bounds__(256) void gather_eot_kernel(const int32_t* __restrict__ tokens,
+                                                         const TX* __restrict__ x, float* __restrict__ y,
+                                                         int n, int L, int c) {
+  const int lane = threadIdx.x & 63;
+  const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seq >= n) return;
+  int best = -2147483647 - 1, at = 0x7fffffff;
+  for (int t = lane; t < L; t += 64) {
+    const int v = tokens[(size_t)seq * L + t];
+    if (v > best) {
+      best = v;
+      at = t;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ob = __shfl_xor(best, o, 64), oa = __shfl_xor(at, o, 64);
+    if (ob > best || (ob == best && oa < at)) {
+      best = ob;
+      at = oa;
+    }
+  }
+  const TX* xr = x + ((size_t)seq * L + at) * c;
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)seq * c);
+  for (int i = lane; i < (c >> 2); i += 64) yr[i] = load4<TX>(xr, i);
+}
+
 // ---- head tail: rows of [n, e] fp32 -> optional L2 normalise -> fp16 / fp32 ------------------
 // (ln_post is a layernorm_kernel launch over the CLS rows and `@ proj` a small GEMM: the first
 // version — one block streaming all of proj per 4 crops — took 85 us cold for 0.2 GFLOP.)
@@ -418,6 +481,43 @@ hipError_t launch_fold_ln(int dtype16, const float* w32, const float* gamma, con
   else if (dtype16 == DT_BF16)
     hipLaunchKernelGGL((fold_ln_kernel<bf16_t>), g, b, 0, s, w32, gamma, beta, bias,
                        reinterpret_cast<bf16_t*>(wf), colsum, bf, n_out, k);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_text_embed(const int32_t* tokens, const float* tok_emb, const float* pos, void* x,
+                             int x_dtype, int n, int L, int c, int vocab, float* rowpart, hipStream_t s) {
+  const int rows = n * L;
+  if (rows <= 0) return hipSuccess;
+  if (c % 4 != 0 || c > kMaxVec * 256) return hipErrorInvalidValue;
+  const dim3 g((rows + 3) / 4), b(256);
+  float2* rp = reinterpret_cast<float2*>(rowpart);
+  if (x_dtype == DT_F32)
+    hipLaunchKernelGGL(text_embed_kernel<float>, g, b, 0, s, tokens, tok_emb, pos,
+                       reinterpret_cast<float*>(x), rows, L, c, vocab, rp);
+  else if (x_dtype == DT_F16)
+    hipLaunchKernelGGL(text_embed_kernel<f16_t>, g, b, 0, s, tokens, tok_emb, pos,
+                       reinterpret_cast<f16_t*>(x), rows, L, c, vocab, rp);
+  else if (x_dtype == DT_BF16)
+    hipLaunchKernelGGL(text_embed_kernel<bf16_t>, g, b, 0, s, tokens, tok_emb, pos,
+                       reinterpret_cast<bf16_t*>(x), rows, L, c, vocab, rp);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_eot(const int32_t* tokens, const void* x, int x_dtype, float* y, int n, int L,
+                             int c, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (c % 4 != 0) return hipErrorInvalidValue;
+  const dim3 g((n + 3) / 4), b(256);
+  if (x_dtype == DT_F32)
+    hipLaunchKernelGGL(gather_eot_kernel<float>, g, b, 0, s, tokens, reinterpret_cast<const float*>(x), y, n, L, c);
+  else if (x_dtype == DT_F16)
+    hipLaunchKernelGGL(gather_eot_kernel<f16_t>, g, b, 0, s, tokens, reinterpret_cast<const f16_t*>(x), y, n, L, c);
+  else if (x_dtype == DT_BF16)
+    hipLaunchKernelGGL(gather_eot_kernel<bf16_t>, g, b, 0, s, tokens, reinterpret_cast<const bf16_t*>(x), y, n, L, c);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

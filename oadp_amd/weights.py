@@ -79,6 +79,48 @@ def synthetic_state_dict(*, image_size=224, patch_size=32, width=768, layers=12,
     return sd
 
 
+def synthetic_text_state_dict(*, context=77, vocab=49408, width=512, layers=12, heads=8, mlp_dim=2048,
+                              embed_dim=512, seed: int = 2) -> dict[str, torch.Tensor]:
+    """Random-init text-tower state_dict (fp32, CPU): the CLIP names without the ``visual.`` prefix."""
+    del heads
+    sd: dict[str, torch.Tensor] = {}
+
+    def ln(prefix: str) -> None:
+        sd[prefix + '.weight'] = 1.0 + _sym(prefix + '.weight', (width,), 0.1, seed)
+        sd[prefix + '.bias'] = _sym(prefix + '.bias', (width,), 0.1, seed)
+
+    sd['token_embedding.weight'] = _sym('token_embedding.weight', (vocab, width), 0.05, seed)
+    sd['positional_embedding'] = _sym('positional_embedding', (context, width), 0.03, seed)
+    for i in range(layers):
+        p = f'transformer.resblocks.{i}.'
+        ln(p + 'ln_1')
+        ln(p + 'ln_2')
+        sd[p + 'attn.in_proj_weight'] = _sym(p + 'attn.in_proj_weight', (3 * width, width), width ** -0.5, seed)
+        sd[p + 'attn.in_proj_bias'] = _sym(p + 'attn.in_proj_bias', (3 * width,), 0.05, seed)
+        sd[p + 'attn.out_proj.weight'] = _sym(p + 'attn.out_proj.weight', (width, width), width ** -0.5, seed)
+        sd[p + 'attn.out_proj.bias'] = _sym(p + 'attn.out_proj.bias', (width,), 0.05, seed)
+        sd[p + 'mlp.c_fc.weight'] = _sym(p + 'mlp.c_fc.weight', (mlp_dim, width), width ** -0.5, seed)
+        sd[p + 'mlp.c_fc.bias'] = _sym(p + 'mlp.c_fc.bias', (mlp_dim,), 0.05, seed)
+        sd[p + 'mlp.c_proj.weight'] = _sym(p + 'mlp.c_proj.weight', (width, mlp_dim), mlp_dim ** -0.5, seed)
+        sd[p + 'mlp.c_proj.bias'] = _sym(p + 'mlp.c_proj.bias', (width,), 0.05, seed)
+    ln('ln_final')
+    sd['text_projection'] = _sym('text_projection', (width, embed_dim), width ** -0.5, seed)
+    return sd
+
+
+def synthetic_tokens(n: int, length: int = 77, vocab: int = 49408, seed: int = 0) -> torch.Tensor:
+    """[n, length] int32 token rows shaped like clip.tokenize output: SOT, words, EOT (the highest id,
+    at a different position per row), zero padding."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    out = torch.zeros(n, length, dtype=torch.int32)
+    for i in range(n):
+        k = int(torch.randint(1, max(2, length - 1), (1,), generator=g))
+        out[i, 0] = vocab - 2
+        out[i, 1:k] = torch.randint(1, vocab - 2, (k - 1,), generator=g, dtype=torch.int32)
+        out[i, k] = vocab - 1
+    return out
+
+
 def synthetic_images(n: int, image_size: int = 224, seed: int = 0) -> torch.Tensor:
     """[n,3,S,S] fp32 ~N(0,1): the shape/statistics of CLIP-normalised crops."""
     return normal('images', (n, 3, image_size, image_size), seed)

@@ -104,3 +104,50 @@ def test_positional_embedding_interpolation_matches_fixture():
     assert pos.shape == (197, arch['width'])
     torch.testing.assert_close(pos, torch.from_numpy(z['pos']), rtol=1e-6, atol=1e-6)
     assert torch.equal(pos[0], sd['visual.positional_embedding'][0])  # CLS row untouched
+
+
+def test_text_oracle_matches_huggingface_clip():
+    """oracle/text_ref.py (encode_text restatement) == HuggingFace CLIPTextModelWithProjection on shared
+    random weights (quick_gelu, causal mask, EOT = argmax of the token ids)."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+
+    from oadp_amd.weights import synthetic_text_state_dict, synthetic_tokens
+    from oracle.text_ref import TextConfig, encode_text_ref
+    arch = dict(context=20, vocab=300, width=128, layers=2, heads=2, mlp_dim=256, embed_dim=64)
+    W = arch['width']
+    sd = synthetic_text_state_dict(**arch)
+    hc = CLIPTextConfig(vocab_size=300, hidden_size=W, intermediate_size=256, projection_dim=64,
+                        num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=20,
+                        hidden_act='quick_gelu', eos_token_id=2, bos_token_id=0, pad_token_id=1)
+    m = CLIPTextModelWithProjection(hc).eval()
+    hs = m.state_dict()
+
+    def put(k, v):
+        assert hs[k].shape == v.shape, (k, hs[k].shape, v.shape)
+        hs[k] = v.clone()
+
+    put('text_model.embeddings.token_embedding.weight', sd['token_embedding.weight'])
+    put('text_model.embeddings.position_embedding.weight', sd['positional_embedding'])
+    for i in range(2):
+        p, q = f'transformer.resblocks.{i}.', f'text_model.encoder.layers.{i}.'
+        w, b = sd[p + 'attn.in_proj_weight'], sd[p + 'attn.in_proj_bias']
+        for j, nm in enumerate(('q_proj', 'k_proj', 'v_proj')):
+            put(q + f'self_attn.{nm}.weight', w[j * W:(j + 1) * W])
+            put(q + f'self_attn.{nm}.bias', b[j * W:(j + 1) * W])
+        put(q + 'self_attn.out_proj.weight', sd[p + 'attn.out_proj.weight'])
+        put(q + 'self_attn.out_proj.bias', sd[p + 'attn.out_proj.bias'])
+        for a, c in (('layer_norm1', 'ln_1'), ('layer_norm2', 'ln_2')):
+            put(q + a + '.weight', sd[p + c + '.weight'])
+            put(q + a + '.bias', sd[p + c + '.bias'])
+        put(q + 'mlp.fc1.weight', sd[p + 'mlp.c_fc.weight'])
+        put(q + 'mlp.fc1.bias', sd[p + 'mlp.c_fc.bias'])
+        put(q + 'mlp.fc2.weight', sd[p + 'mlp.c_proj.weight'])
+        put(q + 'mlp.fc2.bias', sd[p + 'mlp.c_proj.bias'])
+    put('text_model.final_layer_norm.weight', sd['ln_final.weight'])
+    put('text_model.final_layer_norm.bias', sd['ln_final.bias'])
+    put('text_projection.weight', sd['text_projection'].t().contiguous())
+    m.load_state_dict(hs)
+    tok = synthetic_tokens(6, 20, 300)
+    with torch.no_grad():
+        ref = m(input_ids=tok.long()).text_embeds
+    torch.testing.assert_close(encode_text_ref(sd, TextConfig(**arch), tok), ref, rtol=1e-4, atol=1e-4)

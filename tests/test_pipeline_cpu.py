@@ -223,3 +223,18 @@ def test_device_decode_dataset_hands_over_file_bytes(tmp_path):
                               transform=_synth.preprocess(), device_decode='strict')
     with pytest.raises(ValueError):
         [strict[i] for i in range(len(strict))]
+
+
+def test_vild_prompt_tokenisation():
+    """oadp_amd/prompts/vild.py: 74 templates; adaptively_tokenize = SOT ids EOT, zero padded, context
+    trimmed to the longest row, EOT the highest id of every row (what encode_text's argmax relies on)."""
+    from oadp_amd.prompts import vild
+    t = vild.templates()
+    assert len(t) == 74 and all('{}' in s for s in t) and t[0] == 'This is a {}'
+    enc = lambda s: [1 + (hash(w) % 1000) for w in s.split()]
+    tok = vild.adaptively_tokenize(['a photo of a cat', 'dog'], enc)
+    assert tok.dtype == torch.int32 and tok.shape == (2, 7)
+    assert tok[0, 0] == vild.SOT and tok[0, 6] == vild.EOT and tok[1, 2] == vild.EOT and tok[1, 3:].sum() == 0
+    assert (tok.argmax(dim=-1) == torch.tensor([6, 2])).all()
+    with pytest.raises(ValueError):
+        vild.adaptively_tokenize(['w ' * 80], enc)
