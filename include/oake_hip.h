@@ -269,6 +269,11 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
 OAKE_API int oake_debug_set_attention_variant(int variant);
 /* GEMM configuration: -1 = automatic per shape, 0..4 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
+/* x[m,n] (16-bit, in place) += A * W^T + bias — the residual epilogue of out_proj / c_proj.  On the
+ * persistent kernel (large m) d_rowpart [m, 16, 2] fp32 (or NULL) receives (sum, sum of squares) of
+ * every 64-column slice of each output row (the LayerNorm statistics handed to the next GEMM). */
+OAKE_API int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const float* d_bias, void* d_x,
+                            float* d_rowpart, int m, int n, int k, int dtype16, void* stream);
 /* GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside), n < 0 = M slabs of
  * -n tiles (column-major inside). */
 OAKE_API int oake_debug_set_gemm_panel(int panel);

@@ -1170,6 +1170,14 @@ int oake_debug_set_gemm_variant(int variant) {
   return OAKE_OK;
 }
 
+int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const float* d_bias, void* d_x,
+                            float* d_rowpart, int m, int n, int k, int dtype16, void* stream) {
+  GemmArgs a{};
+  a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_x; a.M = m; a.N = n; a.K = k; a.ldo = n;
+  a.rowpart_out = gemm_uses_persistent(m, n, k) ? d_rowpart : nullptr;
+  return dbg(launch_gemm(dtype16, EPI_RESID16, a, reinterpret_cast<hipStream_t>(stream)));
+}
+
 int oake_debug_set_gemm_panel(int panel) {
   oake::g_gemm_panel = panel;
   return OAKE_OK;

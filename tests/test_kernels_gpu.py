@@ -98,6 +98,33 @@ def test_gemm_layernorm_folded(lib, cuda, variant, gelu, dtype, m, n, k):
     torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (2250, 768, 3072), (12800, 512, 256),
+                                   (333, 136, 512), (50, 768, 768)])
+def test_gemm_residual_epilogue(lib, cuda, dtype, m, n, k):
+    """x += A W^T + b in the 16-bit residual stream (out_proj / c_proj), ragged tiles included, plus the
+    per-slice row sums the persistent kernel leaves for the next GEMM's LayerNorm."""
+    g = torch.Generator(device='cpu').manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(dtype).to(cuda)
+    bias = torch.randn(n, generator=g).to(cuda)
+    x0 = torch.randn(m, n, generator=g).to(dtype).to(cuda)
+    x = x0.clone()
+    part = torch.full((m, 16, 2), float('nan'), device=cuda)
+    rc = lib.oake_debug_gemm_resid16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(),
+                                     part.data_ptr(), m, n, k, DT[dtype], _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = x0.float() + a.float() @ w.float().t() + bias
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    torch.testing.assert_close(x.float(), ref, rtol=tol, atol=tol)
+    if m > 1024 and n >= 256 and n % 64 == 0:  # persistent kernel: row statistics were produced
+        got = part[:, :n // 64]
+        assert torch.isfinite(got).all()
+        torch.testing.assert_close(got[..., 0], ref.reshape(m, n // 64, 64).sum(-1), rtol=2e-3, atol=2e-2)
+        torch.testing.assert_close(got[..., 1], (ref * ref).reshape(m, n // 64, 64).sum(-1), rtol=2e-3, atol=2e-2)
+
+
 def _gemm_case(lib, cuda, dtype, m, n, k):
     g = torch.Generator(device='cpu').manual_seed(m * 7 + n * 3 + k)
     a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
