@@ -208,6 +208,13 @@ OAKE_API int oake_encode_text(oake_handle* h, const int32_t* d_tokens, int n, in
 OAKE_API int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width, int* components);
 OAKE_API int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8_t* d_out_hwc,
                      size_t out_capacity, int* height, int* width, void* stream);
+/* A batch of files in one call: the Huffman passes run concurrently on `threads` host threads inside
+ * the library (one image per task), then one upload and the GPU half per image on `stream`.
+ * status[i] = OAKE_OK / OAKE_ERR_UNSUPPORTED / OAKE_ERR_INVALID per image (the call itself fails only
+ * for HIP errors); heights / widths may be NULL. */
+OAKE_API int oake_decode_jpeg_batch(oake_handle* h, int n, const uint8_t* const* h_datas, const size_t* nbytes,
+                           uint8_t* const* d_outs, const size_t* capacities, int* heights, int* widths,
+                           int* status, int threads, void* stream);
 /* The two halves separately, so that the serial half can run in many worker processes:
  * oake_jpeg_entropy_decode — host only, no handle, no GPU: the quantised DCT coefficients of every
  *   component, [component][block row][block column][64] in natural order, MCU-padded (h_coefs NULL:

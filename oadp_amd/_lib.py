@@ -49,6 +49,7 @@ SIGNATURES = {
     'oake_text_create': (_I, [_VP, _I, C.POINTER(C.c_void_p)]),
     'oake_encode_text': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     'oake_jpeg_info': (_I, [_VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'oake_decode_jpeg_batch': (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     'oake_jpeg_entropy_decode': (_I, [_VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_size_t)]),
     'oake_jpeg_reconstruct': (_I, [_VP, _VP, C.c_size_t, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
     'oake_decode_jpeg': (_I, [_VP, _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),

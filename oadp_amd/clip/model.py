@@ -278,6 +278,36 @@ class VisionTransformer:
             _lib.check(self._lib, h, rc, 'oake_decode_jpeg')
         return out
 
+    def decode_jpeg_batch(self, datas: list[bytes], device: torch.device | None = None, *,
+                          threads: int = 16) -> list[torch.Tensor | None]:
+        """``decode_jpeg`` for many files in one native call: the Huffman passes run on ``threads``
+        host threads inside the library (no GIL), the GPU half on the current stream.  Files outside
+        the supported subset come back as ``None`` (decode those with PIL)."""
+        dev = torch.device(device).index if device is not None else None
+        dev = torch.cuda.current_device() if dev is None else dev
+        n = len(datas)
+        if n == 0:
+            return []
+        bufs = [(C.c_uint8 * len(d)).from_buffer_copy(d) for d in datas]
+        sizes = []
+        for b, d in zip(bufs, datas):
+            hh, ww = C.c_int(0), C.c_int(0)
+            ok = self._lib.oake_jpeg_info(b, len(d), C.byref(hh), C.byref(ww), None) == _lib.OAKE_OK
+            sizes.append((hh.value, ww.value) if ok else None)
+        outs = [torch.empty((s[0], s[1], 3), dtype=torch.uint8, device=torch.device('cuda', dev)) if s else None
+                for s in sizes]
+        ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
+        lens = (C.c_size_t * n)(*[len(d) for d in datas])
+        optr = (C.c_void_p * n)(*[C.c_void_p(o.data_ptr()) if o is not None else None for o in outs])
+        caps = (C.c_size_t * n)(*[o.numel() if o is not None else 0 for o in outs])
+        status = (C.c_int * n)()
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            rc = self._lib.oake_decode_jpeg_batch(h, n, ptrs, lens, optr, caps, None, None, status, threads,
+                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_decode_jpeg_batch')
+        return [o if status[i] == _lib.OAKE_OK else None for i, o in enumerate(outs)]
+
     def crop_normalize(self, image_u8: torch.Tensor, boxes_xyxy, *,
                        out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
         """Exact-size (n x n) integer crops + ToTensor + Normalize (blocks of one pyramid level)."""

@@ -17,6 +17,8 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/oake_hip.h"
@@ -1056,6 +1058,78 @@ int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8
   if (rc != JPEG_OK)
     return fail(h, rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID, "jpeg: " + err);
   return jpeg_upload_and_reconstruct(h, s, f, d_out_hwc);
+}
+
+int oake_decode_jpeg_batch(oake_handle* h, int n, const uint8_t* const* h_datas, const size_t* nbytes,
+                           uint8_t* const* d_outs, const size_t* capacities, int* heights, int* widths,
+                           int* status, int threads, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (n < 0) return fail(h, OAKE_ERR_INVALID, "negative batch");
+  if (n == 0) return OAKE_OK;
+  if (!h_datas || !nbytes || !d_outs || !capacities || !status)
+    return fail(h, OAKE_ERR_INVALID, "null pointer");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // 1. headers (serial, microseconds each): which images we take, and how much scratch they need
+  std::vector<JpegFrame> frames(n);
+  std::vector<size_t> coff(n, 0), poff(n, 0);
+  size_t ctotal = 0, ptotal = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = (h_datas[i] && d_outs[i]) ? jpeg_read_frame(h_datas[i], nbytes[i], &frames[i], nullptr)
+                                              : JPEG_INVALID;
+    status[i] = rc == JPEG_OK ? OAKE_OK : (rc == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID);
+    if (status[i] == OAKE_OK && (size_t)frames[i].height * frames[i].width * 3 > capacities[i])
+      status[i] = OAKE_ERR_INVALID;
+    if (heights) heights[i] = rc == JPEG_OK ? frames[i].height : 0;
+    if (widths) widths[i] = rc == JPEG_OK ? frames[i].width : 0;
+    if (status[i] != OAKE_OK) continue;
+    coff[i] = ctotal;
+    poff[i] = ptotal;
+    ctotal += (size_t)frames[i].total_coefs;
+    ptotal += ((size_t)frames[i].total_plane_bytes + 15) & ~(size_t)15;
+  }
+  if (ctotal == 0) return OAKE_OK;
+  const size_t cbytes = ctotal * sizeof(int16_t);
+  if (!h->jp_copied) HIP_TRY(h, hipEventCreateWithFlags(&h->jp_copied, hipEventDisableTiming));
+  HIP_TRY(h, hipEventSynchronize(h->jp_copied));  // the pinned buffer's previous contents are on the device
+  if (cbytes > h->jp_host_cap) {
+    if (h->jp_host) HIP_TRY(h, hipHostFree(h->jp_host));
+    h->jp_host = nullptr;
+    h->jp_host_cap = 0;
+    const size_t cap = cbytes + cbytes / 4 + 4096;
+    HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->jp_host), cap, hipHostMallocDefault));
+    h->jp_host_cap = cap;
+  }
+  int rc;
+  if ((rc = grow(h, s, &h->jp_coefs, &h->jp_coefs_cap, cbytes))) return rc;
+  if ((rc = grow(h, s, &h->jp_planes, &h->jp_planes_cap, ptotal))) return rc;
+  // 2. the Huffman passes: independent serial bit streams, one image per task on `threads` host threads
+  {
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+        if (status[i] != OAKE_OK) continue;
+        const int r2 = jpeg_decode_coefs(h_datas[i], nbytes[i], frames[i], h->jp_host + coff[i], nullptr);
+        if (r2 != JPEG_OK) status[i] = r2 == JPEG_UNSUPPORTED ? OAKE_ERR_UNSUPPORTED : OAKE_ERR_INVALID;
+      }
+    };
+    const int nt = std::max(1, std::min(threads, n));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+  }
+  // 3. one upload, then IDCT + upsampling + colour conversion per image
+  HIP_TRY(h, hipMemcpyAsync(h->jp_coefs, h->jp_host, cbytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipEventRecord(h->jp_copied, s));
+  for (int i = 0; i < n; ++i) {
+    if (status[i] != OAKE_OK) continue;
+    const JpegFrame& f = frames[i];
+    RUN(h, s, "jpeg_reconstruct", 0.0,
+        (double)f.total_coefs * 2 + 2.0 * f.total_plane_bytes + 3.0 * f.height * f.width,
+        launch_jpeg_reconstruct(f, h->jp_coefs + coff[i], h->jp_planes + poff[i], d_outs[i], s));
+  }
+  return OAKE_OK;
 }
 
 int oake_jpeg_reconstruct(oake_handle* h, const uint8_t* h_data, size_t nbytes, const int16_t* h_coefs,

@@ -53,33 +53,17 @@ class CocoImages:
 
 
 class EncodedImage:
-    """Stands in for the PIL image on the device-decode path: the host knows the size and holds the
-    file bytes plus the entropy-decoded DCT coefficients (the serial half of JPEG decoding, done here
-    in the DataLoader worker); IDCT / upsampling / colour conversion happen on the GPU."""
+    """Stands in for the PIL image on the device-decode path: the host only reads the file and its
+    header; Huffman decoding (native threads), IDCT, upsampling and colour conversion happen in the
+    process that owns the GPU (``BaseValidator._images_u8`` -> ``oake_decode_jpeg_batch``)."""
 
-    def __init__(self, data: bytes, size: tuple[int, int], coefs: torch.Tensor) -> None:
+    def __init__(self, data: bytes, size: tuple[int, int]) -> None:
         self.data = data
         self.size = size  # (width, height), as PIL.Image.size
-        self.coefs = coefs  # int16, layout of oake_jpeg_entropy_decode
-
-    def packed(self) -> torch.Tensor:
-        """One 1-D uint8 tensor for the Batch: [nbytes: int64][file bytes][pad to 8][coefficients]."""
-        n = len(self.data)
-        pad = -n % 8
-        head = torch.tensor([n], dtype=torch.int64).view(torch.uint8)
-        body = torch.frombuffer(bytearray(self.data + bytes(pad)), dtype=torch.uint8)
-        return torch.cat([head, body, self.coefs.view(torch.uint8)])
-
-    @staticmethod
-    def unpack(t: torch.Tensor) -> tuple[bytes, torch.Tensor]:
-        n = int(t[:8].view(torch.int64)[0])
-        start = 8 + n + (-n % 8)
-        return t[8:8 + n].numpy().tobytes(), t[start:].view(torch.int16)
 
 
-def jpeg_entropy_decode(data: bytes) -> EncodedImage | None:
-    """Header walk + Huffman pass of liboake_hip.so (host only, no GPU): an ``EncodedImage`` if
-    ``oake_jpeg_reconstruct`` can finish this file on the device, else None."""
+def jpeg_size(data: bytes) -> tuple[int, int] | None:
+    """(width, height) if the device decoder covers this file, else None (host only, no GPU)."""
     import ctypes as C
 
     from .. import _lib
@@ -88,14 +72,7 @@ def jpeg_entropy_decode(data: bytes) -> EncodedImage | None:
     h, w = C.c_int(0), C.c_int(0)
     if lib.oake_jpeg_info(buf, len(data), C.byref(h), C.byref(w), None) != _lib.OAKE_OK:
         return None
-    total = C.c_size_t(0)
-    if lib.oake_jpeg_entropy_decode(buf, len(data), None, 0, C.byref(total)) != _lib.OAKE_OK:
-        return None
-    coefs = torch.empty(total.value, dtype=torch.int16)
-    if lib.oake_jpeg_entropy_decode(buf, len(data), C.c_void_p(coefs.data_ptr()), total.value,
-                                    C.byref(total)) != _lib.OAKE_OK:
-        return None  # corrupt entropy segment: let PIL have the final word on this file
-    return EncodedImage(data, (w.value, h.value), coefs)
+    return w.value, h.value
 
 
 class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
@@ -113,10 +90,10 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
         # True: workers only decode; crop / antialiased-bicubic resize / normalise run on the GPU
         # (csrc/resample.hip, bit-exact with the PIL path) — needs a HIP device in the main process
         self._device_preprocess = device_preprocess or bool(device_decode)
-        # True: for baseline JPEGs the workers run only the Huffman pass; IDCT / upsampling / colour
-        # conversion run on the GPU (csrc/jpeg.hip, bit-identical to PIL); files outside that subset
-        # (progressive, CMYK, PNG, ...) take the reference's own PIL decode in the worker.
-        # 'strict': raise for those instead.
+        # True: the workers only read baseline JPEG files; they are decoded by the process that owns
+        # the GPU (csrc/jpeg.hip: Huffman passes on native threads, the rest on the device,
+        # bit-identical to PIL); files outside that subset (progressive, CMYK, PNG, ...) take the
+        # reference's own PIL decode in the worker.  'strict': raise for those instead.
         self._device_decode = device_decode
         self._output_dir = pathlib.Path(output_dir)
         self._output_dir.mkdir(parents=True, exist_ok=True)
@@ -134,9 +111,10 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
     def _load_image(self, id_: int) -> PIL.Image.Image | EncodedImage:
         path = os.path.join(self.root, self.coco.loadImgs([id_])[0]['file_name'])
         if self._device_decode:
-            enc = jpeg_entropy_decode(pathlib.Path(path).read_bytes())
-            if enc is not None:
-                return enc
+            data = pathlib.Path(path).read_bytes()
+            size = jpeg_size(data)
+            if size is not None:
+                return EncodedImage(data, size)
             if self._device_decode == 'strict':
                 raise ValueError(f'{path}: not a baseline JPEG the device decoder supports')
         return PIL.Image.open(path).convert('RGB')
@@ -163,10 +141,10 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
 
 def image_to_u8(image: PIL.Image.Image | EncodedImage) -> torch.Tensor:
     """RGB PIL image -> uint8 HWC tensor (what the device preprocessing kernels consume); an
-    ``EncodedImage`` -> its file bytes as a 1-D uint8 tensor (decoded by ``BaseValidator._image_u8``)."""
+    ``EncodedImage`` -> its file bytes as a 1-D uint8 tensor (decoded by ``BaseValidator._images_u8``)."""
     import numpy as np
     if isinstance(image, EncodedImage):
-        return image.packed()
+        return torch.frombuffer(bytearray(image.data), dtype=torch.uint8)
     return torch.from_numpy(np.asarray(image.convert('RGB'), dtype=np.uint8).copy())
 
 
@@ -280,7 +258,7 @@ class BaseValidator(ABC, Generic[T]):
 
     def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
                  batch_size: int = 256, device: torch.device | str | None = None,
-                 writer_threads: int = 4, **kwargs) -> None:
+                 writer_threads: int = 4, decode_threads: int = 16, **kwargs) -> None:
         self.name = name
         self._model = model
         self._log_interval = (log or {}).get('interval', 50)
@@ -290,6 +268,7 @@ class BaseValidator(ABC, Generic[T]):
         self._device = torch.device(device)
         self.counters = Counters()
         self._writer_threads = writer_threads
+        self._decode_threads = decode_threads
         self._writer: AsyncWriter | None = None
         self._dataloader = self._build_dataloader(Config(dataloader))
 
@@ -317,12 +296,23 @@ class BaseValidator(ABC, Generic[T]):
     def _n_crops(self, batch: T) -> int:
         return 1
 
-    def _image_u8(self, t: torch.Tensor) -> torch.Tensor:
-        """What ``image_to_u8`` produced -> uint8 HWC image on the device (JPEG bytes are decoded there)."""
-        if t.dim() == 1:
-            data, coefs = EncodedImage.unpack(t)
-            return self._model.visual.decode_jpeg(data, self._device, coefs=coefs)
-        return t.to(self._device, non_blocking=True)
+    def _images_u8(self, ts: list[torch.Tensor]) -> list[torch.Tensor]:
+        """What ``image_to_u8`` produced for every image of a flush -> uint8 HWC images on the device;
+        JPEG file bytes (1-D tensors) are decoded there, all of them in one native call."""
+        out: list[torch.Tensor | None] = [None] * len(ts)
+        enc = [i for i, t in enumerate(ts) if t.dim() == 1]
+        if enc:
+            datas = [ts[i].numpy().tobytes() for i in enc]
+            decoded = self._model.visual.decode_jpeg_batch(datas, self._device, threads=self._decode_threads)
+            for i, d, img in zip(enc, datas, decoded):
+                if img is None:  # entropy segment the device decoder rejects: PIL has the final word
+                    import io
+                    img = image_to_u8(PIL.Image.open(io.BytesIO(d))).to(self._device)
+                out[i] = img
+        for i, t in enumerate(ts):
+            if out[i] is None:
+                out[i] = t.to(self._device, non_blocking=True)
+        return out
 
     def _flush(self, pending: list[T]) -> None:
         if not pending:

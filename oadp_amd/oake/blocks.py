@@ -113,7 +113,7 @@ class Validator(BaseValidator[Batch]):
         exact 224x224 crops of the level image, levels chained by Pillow-exact resizes."""
         ds = self._dataloader.dataset
         v = self._model.visual
-        level = self._image_u8(image_u8)
+        level = image_u8
         h, w = level.shape[:2]
         out = [v.crop_resize_normalize(level, [(0, 0, w, h)], out_dtype=torch.float16)]
         r = ds._r
@@ -130,7 +130,7 @@ class Validator(BaseValidator[Batch]):
     def _encode(self, batches: list[Batch]) -> list[dict]:
         # reference _run_iter (blocks.py:125-135), crops of several images in one encoder pass
         if batches[0].blocks.dtype == torch.uint8:
-            blocks = torch.cat([self._device_blocks(b.blocks) for b in batches])
+            blocks = torch.cat([self._device_blocks(im) for im in self._images_u8([b.blocks for b in batches])])
             counts = [b.bboxes.shape[0] for b in batches]
         else:
             blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)

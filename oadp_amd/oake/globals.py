@@ -45,8 +45,7 @@ class Validator(BaseValidator[Batch]):
             # device preprocessing: one uint8 HWC upload per image, Pillow-exact resize on the GPU
             squash = getattr(self._dataloader.dataset.transform, 'squash', False)
             crops = []
-            for b in batches:
-                image = self._image_u8(b.image)
+            for image in self._images_u8([b.image for b in batches]):
                 h, w = image.shape[:2]
                 crops.append(self._model.visual.crop_resize_normalize(
                     image, [(0, 0, w, h)], squash=squash, out_dtype=torch.float16))

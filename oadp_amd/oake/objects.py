@@ -176,8 +176,8 @@ class Validator(BaseValidator[Batch]):
             # device preprocessing: preprocess(image.crop(box)) for all proposals of an image in
             # three kernel launches, bit-exact with the PIL path
             objects = torch.cat([self._model.visual.crop_resize_normalize(
-                self._image_u8(b.objects), b.crop_boxes, out_dtype=torch.float16)
-                for b in batches])
+                im, b.crop_boxes, out_dtype=torch.float16)
+                for im, b in zip(self._images_u8([b.objects for b in batches]), batches)])
         else:
             objects = torch.cat([b.objects for b in batches])
         masks = torch.cat([b.masks for b in batches])

@@ -127,6 +127,25 @@ def test_device_decode_matches_pillow(cuda, h, w, ss, q, kind):
 
 
 @pytest.mark.gpu
+def test_device_decode_batch(cuda):
+    """oake_decode_jpeg_batch: many files, Huffman passes on native threads; per-image status."""
+    from oadp_amd import clip
+    from oadp_amd.weights import synthetic_state_dict
+    from tests._synth import TINY
+    model, _ = clip.load(synthetic_state_dict(**TINY), max_batch=2)
+    datas = [_encode(_synth(40 + 7 * i, 50 + 11 * i, 'grad' if i % 2 else 'noise', seed=i), quality=60 + 3 * i,
+                     subsampling=i % 3) for i in range(12)]
+    datas.insert(5, _encode(_synth(32, 32, 'grad'), quality=80, progressive=True))  # unsupported -> None
+    datas.insert(9, b'garbage')
+    for threads in (1, 4, 32):
+        outs = model.visual.decode_jpeg_batch(datas, threads=threads)
+        assert outs[5] is None and outs[9] is None
+        for d, o in zip(datas, outs):
+            if o is not None:
+                assert np.array_equal(o.cpu().numpy(), _pil(d))
+
+
+@pytest.mark.gpu
 def test_device_decode_gray_restart_errors(cuda):
     from oadp_amd import clip, _lib
     from oadp_amd.weights import synthetic_state_dict
