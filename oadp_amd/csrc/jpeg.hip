@@ -41,7 +41,8 @@ struct Huff {
   uint8_t vals[256];
   bool present = false;
 
-  void build(const uint8_t* bits, const uint8_t* v, int n) {
+  // false: the code lengths oversubscribe the code space (corrupt DHT)
+  bool build(const uint8_t* bits, const uint8_t* v, int n) {
     memset(look, 0, sizeof(look));
     memset(fast_ac, 0, sizeof(fast_ac));
     memcpy(vals, v, n);
@@ -54,6 +55,7 @@ struct Huff {
           for (int f = 0; f < (1 << (kLook - len)); ++f) look[base + f] = (uint16_t)((len << 8) | v[k]);
         }
       }
+      if (code > (1 << len)) return false;
       maxcode[len] = bits[len - 1] ? code - 1 : -1;
       code <<= 1;
     }
@@ -68,6 +70,7 @@ struct Huff {
       fast_ac[w] = (int32_t)((uint32_t)val << 16) | (run << 8) | (len + mag);
     }
     present = true;
+    return true;
   }
 };
 
@@ -116,7 +119,7 @@ struct BitReader {
     }
     if (len > 16) return -1;
     drop(len);
-    return t.vals[code + t.valoff[len]];
+    return t.vals[(code + t.valoff[len]) & 255];
   }
   inline int receive_extend(int s) {
     if (cnt < s) fill();
@@ -208,7 +211,8 @@ int parse_markers(const uint8_t* d, size_t n, JpegFrame* f, Tables* t, std::stri
         int cnt = 0;
         for (int k = 0; k < 16; ++k) cnt += b[i + 1 + k];
         if (th > 3 || tc > 1 || cnt > 256 || i + 17 + cnt > len) return fail(JPEG_INVALID, "bad DHT");
-        if (t) (tc ? t->ac[th] : t->dc[th]).build(b + i + 1, b + i + 17, cnt);
+        if (t && !(tc ? t->ac[th] : t->dc[th]).build(b + i + 1, b + i + 17, cnt))
+          return fail(JPEG_INVALID, "bad DHT (oversubscribed code lengths)");
         i += 17 + cnt;
       }
     } else if (m == 0xDD) {

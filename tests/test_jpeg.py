@@ -98,6 +98,20 @@ def test_host_huffman_restart_optimized_info():
     prog = _encode(a, quality=80, progressive=True)
     buf = (C.c_uint8 * len(prog)).from_buffer_copy(prog)
     assert lib.oake_jpeg_info(buf, len(prog), None, None, None) == _lib.OAKE_ERR_UNSUPPORTED
+    # fuzz: corrupted files must be rejected or decoded to *something*, never crash the process
+    rng = np.random.default_rng(11)
+    good = _encode(a, quality=85, subsampling=2)
+    for trial in range(300):
+        bad = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            bad[int(rng.integers(2, len(bad)))] = int(rng.integers(0, 256))
+        if trial % 3 == 0:
+            bad = bad[:int(rng.integers(4, len(bad)))]
+        buf = (C.c_uint8 * len(bad)).from_buffer_copy(bytes(bad))
+        total = C.c_size_t(0)
+        if lib.oake_jpeg_entropy_decode(buf, len(bad), None, 0, C.byref(total)) == 0 and total.value < 10 ** 7:
+            out = np.zeros(total.value, np.int16)
+            lib.oake_jpeg_entropy_decode(buf, len(bad), out.ctypes.data_as(C.c_void_p), out.size, C.byref(total))
     junk = bytes(100)
     buf = (C.c_uint8 * len(junk)).from_buffer_copy(junk)
     assert lib.oake_jpeg_info(buf, len(junk), None, None, None) == _lib.OAKE_ERR_INVALID
