@@ -390,14 +390,16 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
   A((void**)&h->stage, h->stage_elems * 4);
   // workspace
   if (!text) A(&h->a_patch, B * h->p2 * h->kpatch * e16());
-  A(&h->x, B * L * C * (h->xdt == DT_F32 ? 4 : 2));
-  A(&h->xn, B * L * C * e16());
-  A(&h->qkv, B * L * 3 * C * e16());
-  A(&h->att, B * L * C * e16());
-  A(&h->hbuf, B * L * F * e16());
+  // (+ B rows: in objects mode the object-token stream rides as rows B*L .. B*L+B of the same matrices)
+  const size_t R = B * L + B;
+  A(&h->x, R * C * (h->xdt == DT_F32 ? 4 : 2));
+  A(&h->xn, R * C * e16());
+  A(&h->qkv, R * 3 * C * e16());
+  A(&h->att, R * C * e16());
+  A(&h->hbuf, R * F * e16());
   A((void**)&h->y, B * C * 4);
-  A((void**)&h->rowstat, (B * L + 2) * 2 * 4);
-  A((void**)&h->rowpart, B * L * 32 * 4);
+  A((void**)&h->rowstat, (R + 2) * 2 * 4);
+  A((void**)&h->rowpart, R * 32 * 4);
   A((void**)&h->e32, B * E * 4);
   A(&h->yn, B * C * e16());
   A(&h->qkv_y, B * 3 * C * e16());
@@ -567,18 +569,24 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
 namespace {
 
 // ---- shared pieces of the two schedules -------------------------------------------------------
+// row0: first residual row the call works on (offsets the row-statistics buffers); A / out already
+// point at that row.
 int gemm(oake_handle* h, hipStream_t s, const char* name, int epi, const void* A, const void* W,
          const float* bias, void* out, int M, int N, int K, int ldo,
-         const float* rowstat = nullptr, const float* colsum = nullptr) {
+         const float* rowstat = nullptr, const float* colsum = nullptr, size_t row0 = 0) {
   GemmArgs a{};
   a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
-  a.rowstat = rowstat; a.colsum = colsum;
-  // row statistics travel GEMM -> GEMM when the main stream's shapes run the persistent kernel
+  a.rowstat = rowstat ? rowstat + row0 * 2 : nullptr;
+  a.colsum = colsum;
+  // row statistics travel GEMM -> GEMM when the stream's shapes run the persistent kernel
+  float* part = h->rowpart + row0 * 32;
   if (h->stat_fused && (epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN)) {
-    a.rowpart_in = h->rowpart;
+    a.rowpart_in = part;
     a.nparts = h->nparts;
   }
-  if (h->stat_fused && epi == EPI_RESID16 && out == h->x) a.rowpart_out = h->rowpart;
+  const char* xb = reinterpret_cast<const char*>(h->x);
+  const bool to_resid = out == xb + row0 * (size_t)ldo * (h->xdt == DT_F32 ? 4 : 2);
+  if (h->stat_fused && epi == EPI_RESID16 && to_resid) a.rowpart_out = part;
   RUN(h, s, name, 2.0 * M * N * K, 0.0, launch_gemm(h->dt16, epi, a, s));
   if (a.rowpart_out) h->nparts = N / 64;
   return OAKE_OK;
@@ -611,49 +619,72 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   return OAKE_OK;
 }
 
-// ln_1 + in-proj of the main token stream -> h->qkv ([T, 3C]; kv_only: columns C.. only)
-int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_only) {
+// ln_1 + in-proj of residual rows [r0, r0 + M) -> the same rows of h->qkv ([., 3C]; kv_only:
+// columns C.. only)
+int in_proj_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, bool kv_only,
+                 const char* name) {
   const int C = h->cfg.width;
   const int n0 = kv_only ? C : 0, N = 3 * C - n0;
-  const size_t es = 2;
-  const char* name = kv_only ? "gemm_kv" : "gemm_qkv";
-  char* out = reinterpret_cast<char*>(h->qkv) + (size_t)n0 * es;
+  const size_t es = 2, xs = h->xdt == DT_F32 ? 4 : 2;
+  char* out = reinterpret_cast<char*>(h->qkv) + (r0 * 3 * C + n0) * es;
+  const char* xr = reinterpret_cast<const char*>(h->x) + r0 * C * xs;
   if (h->xdt == DT_F32) {
-    RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-        launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln1_g, w.ln1_b, h->xn, T, C, s));
+    char* xn = reinterpret_cast<char*>(h->xn) + r0 * C * es;
+    RUN(h, s, "layernorm", 0.0, (double)M * C * 6,
+        launch_layernorm(h->dt16, xr, h->xdt, C, w.ln1_g, w.ln1_b, xn, M, C, s));
     const char* wp = reinterpret_cast<const char*>(w.in_w) + (size_t)n0 * C * es;
-    return gemm(h, s, name, EPI_T16_BIAS, h->xn, wp, w.in_b + n0, out, T, N, C, 3 * C);
+    return gemm(h, s, name, EPI_T16_BIAS, xn, wp, w.in_b + n0, out, M, N, C, 3 * C);
   }
   // 16-bit residual stream: ln_1 folded into the GEMM, which reads the raw residual rows
   if (!h->stat_fused)
-    RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
+    RUN(h, s, "rowstat", 0.0, (double)M * C * 2,
+        launch_rowstat(xr, h->xdt, C, h->rowstat + r0 * 2, M, C, s));
   const char* wp = reinterpret_cast<const char*>(w.in_wf) + (size_t)n0 * C * es;
-  return gemm(h, s, name, EPI_T16_BIAS_LN, h->x, wp, w.in_bf + n0, out, T, N, C, 3 * C, h->rowstat,
-              w.in_cs + n0);
+  return gemm(h, s, name, EPI_T16_BIAS_LN, xr, wp, w.in_bf + n0, out, M, N, C, 3 * C, h->rowstat,
+              w.in_cs + n0, r0);
+}
+
+// attention out-proj (+residual) -> ln_2 + c_fc (+QuickGELU) -> c_proj (+residual) of rows [r0, r0 + M)
+int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, const char* sfx) {
+  const int C = h->cfg.width, F = h->cfg.mlp_dim;
+  const size_t es = 2, xs = h->xdt == DT_F32 ? 4 : 2;
+  char* xr = reinterpret_cast<char*>(h->x) + r0 * C * xs;
+  const char* att = reinterpret_cast<const char*>(h->att) + r0 * C * es;
+  char* hb = reinterpret_cast<char*>(h->hbuf) + r0 * F * es;
+  const std::string n_out = std::string("gemm_out_proj") + sfx, n_fc = std::string("gemm_c_fc") + sfx,
+                    n_pr = std::string("gemm_c_proj") + sfx;
+  const int resid = h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16;
+  int rc;
+  if ((rc = gemm(h, s, n_out.c_str(), resid, att, w.out_w, w.out_b, xr, M, C, C, C, nullptr, nullptr, r0)))
+    return rc;
+  if (h->xdt == DT_F32) {
+    char* xn = reinterpret_cast<char*>(h->xn) + r0 * C * es;
+    RUN(h, s, "layernorm", 0.0, (double)M * C * 6,
+        launch_layernorm(h->dt16, xr, h->xdt, C, w.ln2_g, w.ln2_b, xn, M, C, s));
+    if ((rc = gemm(h, s, n_fc.c_str(), EPI_T16_GELU, xn, w.fc_w, w.fc_b, hb, M, F, C, F))) return rc;
+  } else {
+    // ln_2 folded into c_fc: the GEMM reads the raw residual rows
+    if (!h->stat_fused)
+      RUN(h, s, "rowstat", 0.0, (double)M * C * 2,
+          launch_rowstat(xr, h->xdt, C, h->rowstat + r0 * 2, M, C, s));
+    if ((rc = gemm(h, s, n_fc.c_str(), EPI_T16_GELU_LN, xr, w.fc_wf, w.fc_bf, hb, M, F, C, F, h->rowstat,
+                   w.fc_cs, r0)))
+      return rc;
+  }
+  return gemm(h, s, n_pr.c_str(), resid, hb, w.proj_w, w.proj_b, xr, M, C, F, C, nullptr, nullptr, r0);
+}
+
+int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_only) {
+  return in_proj_rows(h, s, w, 0, T, kv_only, kv_only ? "gemm_kv" : "gemm_qkv");
 }
 
 int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   // attention + out_proj + MLP of the main token stream (qkv already computed)
-  const int C = h->cfg.width, F = h->cfg.mlp_dim, L = h->cur_len, T = nb * L;
+  const int C = h->cfg.width, L = h->cur_len, T = nb * L;
   const int Lp = ((L + 63) / 64) * 64;
   RUN(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
       launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s));
-  int rc;
-  if ((rc = gemm(h, s, "gemm_out_proj", h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16, h->att, w.out_w, w.out_b, h->x, T, C, C, C))) return rc;
-  if (h->xdt == DT_F32) {
-    RUN(h, s, "layernorm", 0.0, (double)T * C * 6,
-        launch_layernorm(h->dt16, h->x, h->xdt, C, w.ln2_g, w.ln2_b, h->xn, T, C, s));
-    if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU, h->xn, w.fc_w, w.fc_b, h->hbuf, T, F, C, F))) return rc;
-  } else {
-    // ln_2 folded into c_fc: the GEMM reads the raw residual rows
-    if (!h->stat_fused)
-      RUN(h, s, "rowstat", 0.0, (double)T * C * 2, launch_rowstat(h->x, h->xdt, C, h->rowstat, T, C, s));
-    if ((rc = gemm(h, s, "gemm_c_fc", EPI_T16_GELU_LN, h->x, w.fc_wf, w.fc_bf, h->hbuf, T, F, C, F,
-                   h->rowstat, w.fc_cs)))
-      return rc;
-  }
-  if ((rc = gemm(h, s, "gemm_c_proj", h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16, h->hbuf, w.proj_w, w.proj_b, h->x, T, C, F, C))) return rc;
-  return OAKE_OK;
+  return mlp_rows(h, s, w, 0, T, "");
 }
 
 // ln_post over `nb` rows (x + i*row_stride) -> @ proj -> optional L2 normalise -> out
@@ -853,7 +884,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
   HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const oake_config& c = h->cfg;
-  const int C = c.width, F = c.mlp_dim, L = h->tokens;
+  const int C = c.width, L = h->tokens;
   const size_t img_bytes = (size_t)3 * c.image_size * c.image_size * dtype_size(in_dtype);
   const size_t mask_bytes = (size_t)h->p2 * dtype_size(mask_dtype);
   const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
@@ -865,35 +896,53 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
     const char* masks = reinterpret_cast<const char*>(d_masks) + (size_t)b0 * mask_bytes;
     char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
     if ((rc = patch_embed(h, s, imgs, in_dtype, nb))) return rc;
-    // Hooks.transformer_forward_pre (objects.py:215-221): y = x[[0]] (after ln_pre)
-    RUN(h, s, "copy_cls", 0.0, 2.0 * nb * C * 4, launch_copy_cls(h->x, h->xdt, h->y, nb, L, C, s));
+    // Hooks.transformer_forward_pre (objects.py:215-221): y = x[[0]] (after ln_pre).  The object
+    // tokens live as rows T .. T+nb of the SAME matrices as the patch tokens, so that every layer's
+    // GEMMs carry both streams in one launch (they share the weights); only the attention differs.
+    const size_t xs = h->xdt == DT_F32 ? 4 : 2;
+    char* yrows = reinterpret_cast<char*>(h->x) + (size_t)T * C * xs;
+    RUN(h, s, "copy_cls", 0.0, 2.0 * nb * C * xs,
+        hipMemcpy2DAsync(yrows, (size_t)C * xs, h->x, (size_t)L * C * xs, (size_t)C * xs, nb,
+                         hipMemcpyDeviceToDevice, s));
+    if (h->stat_fused)  // ... and so do their row statistics (slot 0 of the CLS rows)
+      HIP_TRY(h, hipMemcpy2DAsync(h->rowpart + (size_t)T * 32, 32 * 4, h->rowpart, (size_t)L * 32 * 4, 8, nb,
+                                  hipMemcpyDeviceToDevice, s));
+    const char* qkv_y = reinterpret_cast<const char*>(h->qkv) + (size_t)T * 3 * C * 2;
+    char* att_y = reinterpret_cast<char*>(h->att) + (size_t)T * C * 2;
     for (int l = 0; l < c.layers; ++l) {
       const LayerW& w = h->layers[l];
       const bool last = (l == c.layers - 1);
-      // ln_1 + in-proj of the main stream: k/v of patch rows serve both streams (Appendix C #1)
-      // (last layer: the main stream's q is dead (Appendix C #2) — k and v only)
-      if ((rc = main_in_proj(h, s, w, T, last))) return rc;
-      // object-token stream (Hooks.residual_attention_block_forward_pre, objects.py:223-247)
-      RUN(h, s, "layernorm_y", 0.0, (double)nb * C * 6,
-          launch_layernorm(h->dt16, h->y, DT_F32, C, w.ln1_g, w.ln1_b, h->yn, nb, C, s));
-      if ((rc = gemm(h, s, "gemm_qkv_y", EPI_T16_BIAS, h->yn, w.in_w, w.in_b, h->qkv_y, nb, 3 * C, C, 3 * C)))
-        return rc;
+      if (!last) {
+        // ln_1 + in-proj of both streams; k/v of the patch rows serve both (Appendix C #1)
+        if ((rc = in_proj_rows(h, s, w, 0, T + nb, false, "gemm_qkv"))) return rc;
+      } else {
+        // last layer: the main stream's q is dead and its block is never run (Appendix C #2) —
+        // k and v of the patch rows, then the object tokens on their own (small GEMMs, once)
+        if ((rc = in_proj_rows(h, s, w, 0, T, true, "gemm_kv"))) return rc;
+        const bool fused = h->stat_fused;
+        h->stat_fused = false;  // (the small kernels take (rstd, -mean rstd) from a rowstat pass)
+        rc = in_proj_rows(h, s, w, T, nb, false, "gemm_qkv_y");
+        h->stat_fused = fused;
+        if (rc) return rc;
+      }
+      // object-token attention (Hooks.residual_attention_block_forward_pre, objects.py:223-247)
       RUN(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
-          launch_object_attention(h->dt16, h->qkv, h->qkv_y, masks, mask_dtype, h->att_y, nb, L,
-                                  c.heads, s));
-      if ((rc = gemm(h, s, "gemm_out_proj_y", EPI_RESID, h->att_y, w.out_w, w.out_b, h->y, nb, C, C, C)))
-        return rc;
-      RUN(h, s, "layernorm_y", 0.0, (double)nb * C * 6,
-          launch_layernorm(h->dt16, h->y, DT_F32, C, w.ln2_g, w.ln2_b, h->yn, nb, C, s));
-      if ((rc = gemm(h, s, "gemm_c_fc_y", EPI_T16_GELU, h->yn, w.fc_w, w.fc_b, h->h_y, nb, F, C, F)))
-        return rc;
-      if ((rc = gemm(h, s, "gemm_c_proj_y", EPI_RESID, h->h_y, w.proj_w, w.proj_b, h->y, nb, C, F, C)))
-        return rc;
-      // main stream forward of this block (skipped for the last block: its output is replaced by
-      // y in Hooks.transformer_forward, objects.py:249-258)
-      if (!last && (rc = main_block_tail(h, s, w, nb))) return rc;
+          launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s));
+      if (!last) {
+        const int Lp = ((L + 63) / 64) * 64;
+        RUN(h, s, "attention", 4.0 * nb * c.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
+            launch_attention(h->dt16, h->qkv, h->att, nb, L, c.heads, 0, s));
+        if ((rc = mlp_rows(h, s, w, 0, T + nb, ""))) return rc;
+      } else {
+        const bool fused = h->stat_fused;
+        h->stat_fused = false;
+        rc = mlp_rows(h, s, w, T, nb, "_y");
+        h->stat_fused = fused;
+        if (rc) return rc;
+      }
     }
-    if ((rc = head(h, s, h->y, DT_F32, (long)C, outp, out_dtype, normalize, nb))) return rc;
+    // Hooks.transformer_forward (objects.py:249-258): the block stack's output is y
+    if ((rc = head(h, s, yrows, h->xdt, (long)C, outp, out_dtype, normalize, nb))) return rc;
   }
   return OAKE_OK;
 }
