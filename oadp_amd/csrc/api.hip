@@ -27,6 +27,7 @@
 namespace oake {
 extern int g_attention_use_tr;
 extern int g_attention_q32;
+extern int g_attention_coop;
 extern int g_gemm_variant;
 extern int g_gemm_panel;
 extern unsigned long long* g_gemm_trace;
@@ -1315,6 +1316,7 @@ int oake_debug_set_attention_variant(int variant) {
   // bit 0: ds_read_b64_tr_b16 V fragments (else 16-bit gathers); bit 1: 32 queries per wave (else 64)
   oake::g_attention_use_tr = (variant & 1) ? 1 : 0;
   oake::g_attention_q32 = (variant & 2) ? 1 : 0;
+  oake::g_attention_coop = (variant & 4) ? 1 : 0;
   return OAKE_OK;
 }
 

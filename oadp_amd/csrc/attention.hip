@@ -298,6 +298,187 @@ __global__ __launch_bounds__(256) void object_attention_kernel(const T* __restri
   out[(size_t)n * C + h * kHeadDim + lane] = to16<T>(acc * inv);
 }
 
+// attention_coop_kernel: for L > 64 (objects mode L = 197, text L = 77).  With one wave per 32-query
+// block every wave streams ALL keys and values of its (crop, head): at L = 197 that is 7 waves
+// re-reading the same K / V from L2 (2.2 GB per launch, 10 TB/s — the kernel's bound).  Here the four
+// waves of a block own 4 x 32 consecutive queries of ONE (crop, head) and share each 64-key chunk of K
+// and V through LDS: loaded once per block (2 blocks per head at L = 197), register-prefetched one
+// chunk ahead so the global latency hides under the previous chunk's MFMAs.  Per-wave arithmetic is
+// attention_kernel<T, true, 2>'s: S^T = K Q^T, in-register online softmax, P as the PV B operand, V
+// through ds_read_b64_tr_b16.
+template <typename T>
+__global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict__ qkv,
+                                                             T* __restrict__ out, int L, int H, int QG,
+                                                             int causal) {
+  typedef typename T16<T>::vec8 vec8;
+  constexpr int MT = 2;
+  __shared__ __attribute__((aligned(16))) T ks[64 * kVStride];
+  __shared__ __attribute__((aligned(16))) T vs[64 * kVStride];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int qg = blockIdx.x % QG;
+  const int h = (blockIdx.x / QG) % H;
+  const int img = blockIdx.x / (QG * H);
+  const int C = H * kHeadDim;
+  const size_t ld = (size_t)3 * C;
+  const T* base = qkv + (size_t)img * L * ld + h * kHeadDim;
+  const int fr = lane & 15;
+  const int g = lane >> 4;
+  const int q0 = qg * 128 + wid * 32;
+  const bool active = q0 < L;  // (inactive waves still load and synchronise)
+
+  vec8 qf[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int r = q0 + mt * 16 + fr;
+    r = r < L ? r : L - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      qf[mt][kk] = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + kk * 32 + g * 8);
+  }
+  float m_run[MT], l_run[MT];
+  f32x4 oacc[4][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    m_run[mt] = -1e30f;
+    l_run[mt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // cooperative chunk load: thread -> rows (tid>>3) and (tid>>3)+32, 16-B chunk tid&7, of K and of V
+  const int lr = tid >> 3, lc = tid & 7;
+  // (macros, not lambdas: register arrays captured by a lambda end up in scratch)
+  uint4 kreg0, kreg1, vreg0, vreg1;
+#define OAKE_FETCH(k0_)                                                                      \
+  do {                                                                                       \
+    int _r0 = (k0_) + lr, _r1 = (k0_) + lr + 32;                                             \
+    _r0 = _r0 < L ? _r0 : L - 1; /* finite filler for padded keys (their P is exactly 0) */  \
+    _r1 = _r1 < L ? _r1 : L - 1;                                                             \
+    kreg0 = *reinterpret_cast<const uint4*>(base + (size_t)_r0 * ld + C + lc * 8);           \
+    vreg0 = *reinterpret_cast<const uint4*>(base + (size_t)_r0 * ld + 2 * C + lc * 8);       \
+    kreg1 = *reinterpret_cast<const uint4*>(base + (size_t)_r1 * ld + C + lc * 8);           \
+    vreg1 = *reinterpret_cast<const uint4*>(base + (size_t)_r1 * ld + 2 * C + lc * 8);       \
+  } while (0)
+#define OAKE_PUBLISH()                                                                       \
+  do {                                                                                       \
+    *reinterpret_cast<uint4*>(ks + lr * kVStride + lc * 8) = kreg0;                          \
+    *reinterpret_cast<uint4*>(vs + lr * kVStride + lc * 8) = vreg0;                          \
+    *reinterpret_cast<uint4*>(ks + (lr + 32) * kVStride + lc * 8) = kreg1;                   \
+    *reinterpret_cast<uint4*>(vs + (lr + 32) * kVStride + lc * 8) = vreg1;                   \
+  } while (0)
+
+  const int nchunks = (L + 63) >> 6;
+  OAKE_FETCH(0);
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int k0 = kc * 64;
+    OAKE_PUBLISH();
+    __syncthreads();
+    if (kc + 1 < nchunks) OAKE_FETCH(k0 + 64);  // in flight under this chunk's arithmetic
+    // a chunk entirely after this wave's last query is masked out completely under the causal mask
+    const bool skip = !active || (causal && k0 > q0 + 31);
+    if (!skip) {
+      f32x4 sacc[4][MT];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const vec8 kf = *reinterpret_cast<const vec8*>(ks + (kt * 16 + fr) * kVStride + kk * 32 + g * 8);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
+        }
+      vec8 pf[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kt * 16 + 4 * g + r;
+            float sv = sacc[kt][mt][r];
+            // (skipping the masking for entirely valid 16-key tiles behind a uniform branch measured slower)
+            sv = (key < L && (!causal || key <= q0 + mt * 16 + fr)) ? sv : -1e30f;
+            sacc[kt][mt][r] = sv;
+            mx = fmaxf(mx, sv);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[mt], mx);
+        const float alpha = __expf(m_run[mt] - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(sacc[kt][mt][r] - m_new);
+            sacc[kt][mt][r] = p;
+            sum += p;
+          }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l_run[mt] = l_run[mt] * alpha + sum;
+        m_run[mt] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          oacc[dt][mt][0] *= alpha;
+          oacc[dt][mt][1] *= alpha;
+          oacc[dt][mt][2] *= alpha;
+          oacc[dt][mt][3] *= alpha;
+        }
+#pragma unroll
+        for (int ksx = 0; ksx < 2; ++ksx) {
+          vec8 p8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p8[j] = to16<T>(sacc[2 * ksx + (j >> 2)][mt][j & 3]);
+          pf[mt][ksx] = p8;
+        }
+      }
+#pragma unroll
+      for (int ksx = 0; ksx < 2; ++ksx)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int sub = fr >> 2, c4 = (fr & 3) * 4;
+          const T* p0 = vs + (32 * ksx + 4 * g + sub) * kVStride + dt * 16 + c4;
+          const T* p1 = p0 + 16 * kVStride;
+          typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p1));
+          s16x8 both;
+          both[0] = lo[0]; both[1] = lo[1]; both[2] = lo[2]; both[3] = lo[3];
+          both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
+          const vec8 vf = __builtin_bit_cast(vec8, both);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ksx], oacc[dt][mt]);
+        }
+    }
+    __syncthreads();  // every wave is done with this chunk's K / V before the next publish
+  }
+
+#undef OAKE_FETCH
+#undef OAKE_PUBLISH
+  if (!active) return;
+  T* obase = out + (size_t)img * L * C + h * kHeadDim;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int q = q0 + mt * 16 + fr;
+    if (q >= L) continue;
+    const float inv = 1.0f / l_run[mt];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 o = oacc[dt][mt];
+      *reinterpret_cast<uint2*>(obase + (size_t)q * C + dt * 16 + 4 * g) =
+          pack4<T>(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+    }
+  }
+}
+
 __global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[256];
   const int lane = threadIdx.x;
@@ -315,6 +496,9 @@ int g_attention_use_tr = 1;
 
 // 0 = 64 queries per wave, 1 = 32 queries per wave (half the registers, twice the waves)
 int g_attention_q32 = 1;
+
+// 1 = sequences longer than one key chunk share K / V through LDS (attention_coop_kernel)
+int g_attention_coop = 1;
 
 template <typename T, int MT>
 static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, int causal,
@@ -335,6 +519,19 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
   if (n <= 0) return hipSuccess;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
+  if (g_attention_coop && g_attention_use_tr && L > 64) {
+    const int QG = (L + 127) / 128;
+    const dim3 grid(n * heads * QG), blk(256);
+    if (dtype16 == DT_F16)
+      hipLaunchKernelGGL(attention_coop_kernel<f16_t>, grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
+                         reinterpret_cast<f16_t*>(out), L, heads, QG, causal);
+    else if (dtype16 == DT_BF16)
+      hipLaunchKernelGGL(attention_coop_kernel<bf16_t>, grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
+                         reinterpret_cast<bf16_t*>(out), L, heads, QG, causal);
+    else
+      return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (dtype16 == DT_F16) {
     if (g_attention_q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, causal, s);
     else attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, causal, s);
