@@ -28,6 +28,7 @@ namespace oake {
 extern int g_attention_use_tr;
 extern int g_attention_q32;
 extern int g_attention_coop;
+extern int g_attention_fuse_obj;
 extern int g_gemm_variant;
 extern int g_gemm_panel;
 extern unsigned long long* g_gemm_trace;
@@ -926,13 +927,17 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
         h->stat_fused = fused;
         if (rc) return rc;
       }
-      // object-token attention (Hooks.residual_attention_block_forward_pre, objects.py:223-247)
-      RUN(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
-          launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s));
+      // object-token attention (Hooks.residual_attention_block_forward_pre, objects.py:223-247): on an
+      // idle wave of the main stream's attention launch when there is one, else its own kernel
+      const bool fuse = !last && attention_fuses_object_token(L);
+      if (!fuse)
+        RUN(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
+            launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s));
       if (!last) {
         const int Lp = ((L + 63) / 64) * 64;
         RUN(h, s, "attention", 4.0 * nb * c.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
-            launch_attention(h->dt16, h->qkv, h->att, nb, L, c.heads, 0, s));
+            launch_attention(h->dt16, h->qkv, h->att, nb, L, c.heads, 0, s, fuse ? qkv_y : nullptr,
+                             fuse ? masks : nullptr, mask_dtype, fuse ? att_y : nullptr));
         if ((rc = mlp_rows(h, s, w, 0, T + nb, ""))) return rc;
       } else {
         const bool fused = h->stat_fused;
@@ -1317,6 +1322,7 @@ int oake_debug_set_attention_variant(int variant) {
   oake::g_attention_use_tr = (variant & 1) ? 1 : 0;
   oake::g_attention_q32 = (variant & 2) ? 1 : 0;
   oake::g_attention_coop = (variant & 4) ? 1 : 0;
+  oake::g_attention_fuse_obj = (variant & 8) ? 1 : 0;
   return OAKE_OK;
 }
 

@@ -306,18 +306,32 @@ __global__ __launch_bounds__(256) void object_attention_kernel(const T* __restri
 // chunk ahead so the global latency hides under the previous chunk's MFMAs.  Per-wave arithmetic is
 // attention_kernel<T, true, 2>'s: S^T = K Q^T, in-register online softmax, P as the PV B operand, V
 // through ds_read_b64_tr_b16.
+// Objects mode: the reference Hooks' object token (one query per crop: keys = patch rows 1..L-1 with
+// bias -100 * mask, plus the token's own k / v; oadp/oake/objects.py:232-247) rides on the block's
+// first idle wave (L = 197: the last block has 69 queries on three waves) — the K / V chunks it needs
+// are already in LDS.  It runs the same S / softmax / PV machinery with its query in every column;
+// key 0 (the CLS row, not a key of the object token) is re-scored with the token's own key, and the
+// V row it dragged in is swapped for the token's own v at the end.
+struct ObjArgs {
+  const void* qkv_y;   // [n, 3C] q/k/v of the object tokens (nullptr: no object token)
+  const void* mask;    // [n, L-1]
+  void* out_y;         // [n, C]
+  int mask_f16;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict__ qkv,
                                                              T* __restrict__ out, int L, int H, int QG,
-                                                             int causal) {
+                                                             int causal, ObjArgs obj) {
   typedef typename T16<T>::vec8 vec8;
   constexpr int MT = 2;
   __shared__ __attribute__((aligned(16))) T ks[64 * kVStride];
   __shared__ __attribute__((aligned(16))) T vs[64 * kVStride];
+  __shared__ float mbias[256];  // objects mode: -100 * mask of the crop's patch keys, indexed by key
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wid = tid >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the object-token branches are scalar)
   const int qg = blockIdx.x % QG;
   const int h = (blockIdx.x / QG) % H;
   const int img = blockIdx.x / (QG * H);
@@ -327,16 +341,40 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
   const int fr = lane & 15;
   const int g = lane >> 4;
   const int q0 = qg * 128 + wid * 32;
-  const bool active = q0 < L;  // (inactive waves still load and synchronise)
+  // the object token takes the first wave of the last block that has no queries of its own
+  const bool is_obj = obj.qkv_y != nullptr && qg == QG - 1 && q0 >= L && q0 - 32 < L;
+  const bool active = q0 < L || is_obj;  // (inactive waves still load and synchronise)
+  const T* yb = reinterpret_cast<const T*>(obj.qkv_y) + (size_t)img * ld + h * kHeadDim;
 
   vec8 qf[MT][2];
+  float s_self = 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int r = q0 + mt * 16 + fr;
     r = r < L ? r : L - 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
-      qf[mt][kk] = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + kk * 32 + g * 8);
+      qf[mt][kk] = is_obj ? *reinterpret_cast<const vec8*>(yb + kk * 32 + g * 8)
+                          : *reinterpret_cast<const vec8*>(base + (size_t)r * ld + kk * 32 + g * 8);
+  }
+  if (obj.qkv_y != nullptr && qg == QG - 1 && tid < 256) {
+    // (visible after the first chunk's barrier; per-element global loads in the softmax loop made the
+    // object token's wave the slowest of its block)
+    float mval = 0.f;
+    if (tid >= 1 && tid < L)
+      mval = obj.mask_f16 ? (float)reinterpret_cast<const f16_t*>(obj.mask)[(size_t)img * (L - 1) + tid - 1]
+                          : reinterpret_cast<const float*>(obj.mask)[(size_t)img * (L - 1) + tid - 1];
+    mbias[tid] = -100.0f * mval;
+  }
+  if (is_obj) {  // q_y . k_y: the four lane groups hold d = 32 kk + 8 g + j between them
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const vec8 kv = *reinterpret_cast<const vec8*>(yb + C + kk * 32 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_self += to32<T>(qf[0][kk][j]) * to32<T>(kv[j]);
+    }
+    s_self += __shfl_xor(s_self, 16, 64);
+    s_self += __shfl_xor(s_self, 32, 64);
   }
   float m_run[MT], l_run[MT];
   f32x4 oacc[4][MT];
@@ -378,7 +416,7 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
     __syncthreads();
     if (kc + 1 < nchunks) OAKE_FETCH(k0 + 64);  // in flight under this chunk's arithmetic
     // a chunk entirely after this wave's last query is masked out completely under the causal mask
-    const bool skip = !active || (causal && k0 > q0 + 31);
+    const bool skip = !active || (causal && !is_obj && k0 > q0 + 31);
     if (!skip) {
       f32x4 sacc[4][MT];
 #pragma unroll
@@ -397,17 +435,31 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         float mx = -1e30f;
+        if (is_obj) {  // (one scalar branch around the whole tile, not one per score)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+          for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = k0 + kt * 16 + 4 * g + r;
-            float sv = sacc[kt][mt][r];
-            // (skipping the masking for entirely valid 16-key tiles behind a uniform branch measured slower)
-            sv = (key < L && (!causal || key <= q0 + mt * 16 + fr)) ? sv : -1e30f;
-            sacc[kt][mt][r] = sv;
-            mx = fmaxf(mx, sv);
-          }
+            for (int r = 0; r < 4; ++r) {
+              const int key = k0 + kt * 16 + 4 * g + r;
+              float sv = sacc[kt][mt][r];
+              // the CLS row (key 0) is not a key of the object token: its own key instead
+              sv = key == 0 ? s_self : (key < L ? sv + mbias[key & 255] : -1e30f);
+              sacc[kt][mt][r] = sv;
+              mx = fmaxf(mx, sv);
+            }
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = k0 + kt * 16 + 4 * g + r;
+              float sv = sacc[kt][mt][r];
+              // (skipping the masking for entirely valid 16-key tiles behind a uniform branch measured slower)
+              sv = (key < L && (!causal || key <= q0 + mt * 16 + fr)) ? sv : -1e30f;
+              sacc[kt][mt][r] = sv;
+              mx = fmaxf(mx, sv);
+            }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run[mt], mx);
@@ -464,6 +516,29 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
 #undef OAKE_FETCH
 #undef OAKE_PUBLISH
   if (!active) return;
+  if (is_obj) {
+    // every query column holds the object token; lanes fr == 0 write it.  The PV product used V row 0
+    // (the CLS row) with the weight of the token's own key: swap in the token's own v.
+    const float inv = 1.0f / l_run[0];
+    const float p0 = __expf(s_self - m_run[0]) * inv;
+    T* oy = reinterpret_cast<T*>(obj.out_y) + (size_t)img * C + h * kHeadDim;
+    if (fr == 0) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + 4 * g;
+        typedef typename T16<T>::vec4 vec4;
+        const vec4 vy = __builtin_bit_cast(vec4, *reinterpret_cast<const uint2*>(yb + 2 * C + d));
+        const vec4 vc = __builtin_bit_cast(vec4, *reinterpret_cast<const uint2*>(base + 2 * C + d));
+        const f32x4 o = oacc[dt][0];
+        *reinterpret_cast<uint2*>(oy + d) =
+            pack4<T>(o[0] * inv + p0 * (to32<T>(vy[0]) - to32<T>(vc[0])),
+                     o[1] * inv + p0 * (to32<T>(vy[1]) - to32<T>(vc[1])),
+                     o[2] * inv + p0 * (to32<T>(vy[2]) - to32<T>(vc[2])),
+                     o[3] * inv + p0 * (to32<T>(vy[3]) - to32<T>(vc[3])));
+      }
+    }
+    return;
+  }
   T* obase = out + (size_t)img * L * C + h * kHeadDim;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -499,6 +574,8 @@ int g_attention_q32 = 1;
 
 // 1 = sequences longer than one key chunk share K / V through LDS (attention_coop_kernel)
 int g_attention_coop = 1;
+// 1 = objects mode: the object token's attention rides on an idle wave of that kernel
+int g_attention_fuse_obj = 1;
 
 template <typename T, int MT>
 static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, int causal,
@@ -514,20 +591,30 @@ static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, i
     hipLaunchKernelGGL((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
 }
 
+bool attention_fuses_object_token(int L) {
+  // needs the cooperative kernel and a wave without queries in the last block of each head
+  const int tail = L - 128 * ((L + 127) / 128 - 1);
+  return g_attention_coop && g_attention_use_tr && g_attention_fuse_obj && L > 64 && L <= 256 && tail <= 96;
+}
+
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
-                            int causal, hipStream_t s) {
+                            int causal, hipStream_t s, const void* qkv_y, const void* mask,
+                            int mask_dtype, void* out_y) {
   if (n <= 0) return hipSuccess;
+  if (qkv_y != nullptr && !attention_fuses_object_token(L)) return hipErrorInvalidValue;
+  if (qkv_y != nullptr && mask_dtype != DT_F32 && mask_dtype != DT_F16) return hipErrorInvalidValue;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
   if (g_attention_coop && g_attention_use_tr && L > 64) {
     const int QG = (L + 127) / 128;
     const dim3 grid(n * heads * QG), blk(256);
+    const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
     if (dtype16 == DT_F16)
       hipLaunchKernelGGL(attention_coop_kernel<f16_t>, grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
-                         reinterpret_cast<f16_t*>(out), L, heads, QG, causal);
+                         reinterpret_cast<f16_t*>(out), L, heads, QG, causal, obj);
     else if (dtype16 == DT_BF16)
       hipLaunchKernelGGL(attention_coop_kernel<bf16_t>, grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
-                         reinterpret_cast<bf16_t*>(out), L, heads, QG, causal);
+                         reinterpret_cast<bf16_t*>(out), L, heads, QG, causal, obj);
     else
       return hipErrorInvalidValue;
     return hipGetLastError();

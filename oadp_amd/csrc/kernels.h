@@ -95,8 +95,12 @@ hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, 
 // ---- attention ---------------------------------------------------------------------------
 // qkv [n*L, 3*H*64] 16-bit (q pre-scaled by 1/8) -> out [n*L, H*64] 16-bit. Full self-attention.
 // causal != 0: key j is visible to query i only if j <= i (text tower)
+// qkv_y / mask / out_y (optional, only when attention_fuses_object_token(L)): the object tokens'
+// attention (launch_object_attention's job) done by the same launch.
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
-                            int causal, hipStream_t s);
+                            int causal, hipStream_t s, const void* qkv_y = nullptr,
+                            const void* mask = nullptr, int mask_dtype = 0, void* out_y = nullptr);
+bool attention_fuses_object_token(int L);
 
 // Object-token attention (oadp/oake/objects.py:232-247): one query per crop (qkv_y row n),
 // keys/values = patch rows 1..L-1 of qkv_x plus the object token's own k/v (qkv_y);

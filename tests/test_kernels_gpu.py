@@ -182,7 +182,7 @@ def test_attention(lib, cuda, dtype, n, l, heads, use_tr):
         assert rc == 0
         torch.cuda.synchronize()
     finally:
-        lib.oake_debug_set_attention_variant(7)
+        lib.oake_debug_set_attention_variant(15)
     ref = _attention_ref(qkv, n, l, heads)
     tol = 3e-3 if dtype == torch.float16 else 2e-2
     torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
