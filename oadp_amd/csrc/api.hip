@@ -100,7 +100,7 @@ struct oake_handle {
   bool stat_fused = false;    // this pass: statistics via rowpart (else the rowstat kernel)
   int nparts = 0;             // valid slices per row in rowpart (1 after embed, width/64 after a GEMM)
   float* e32 = nullptr;       // [B, embed] fp32 head projection
-  void *yn = nullptr, *qkv_y = nullptr, *att_y = nullptr, *h_y = nullptr;
+  void* yn = nullptr;         // [B, C] 16-bit: ln_post output (head input)
 
   // resample scratch (grown on demand)
   ResampleJob* rs_jobs = nullptr;
@@ -269,7 +269,7 @@ void oake_destroy(oake_handle* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
-                  h->yn, h->qkv_y, h->att_y, h->h_y, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
+                  h->yn, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
                   h->rowstat, h->rowpart, h->jp_coefs, h->jp_planes, h->tok_emb};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -404,9 +404,6 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
   A((void**)&h->rowpart, R * 32 * 4);
   A((void**)&h->e32, B * E * 4);
   A(&h->yn, B * C * e16());
-  A(&h->qkv_y, B * 3 * C * e16());
-  A(&h->att_y, B * C * e16());
-  A(&h->h_y, B * F * e16());
   if (rc != OAKE_OK) {
     g_create_error = h->err;
     oake_destroy(h);

@@ -76,9 +76,6 @@ hipError_t launch_embed_ln_pre(void* x, int x_dtype, const float* cls, const flo
 hipError_t launch_rowsums(const void* x, int x_dtype, long x_row_stride, float* rowpart, int rows,
                           int c, hipStream_t s);
 
-// y[n, :] (fp32) = x[n*L + 0, :]  (objects mode: object-token stream starts as the CLS row)
-hipError_t launch_copy_cls(const void* x, int x_dtype, float* y, int n, int L, int c, hipStream_t s);
-
 // ---- text tower glue (oadp/prompts/vild.py -> clip encode_text) ------------------------------
 // x[n*L + t, :] = tok_emb[tokens[n*L + t], :] + pos[t, :]  (residual-stream type);  rowpart as in
 // launch_embed_ln_pre (slot 0 = row sums) or nullptr

@@ -200,15 +200,6 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(TX* __restrict__ x,
   }
 }
 
-template <typename TX>
-__global__ void copy_cls_kernel(const TX* __restrict__ x, float* __restrict__ y, int n, int L, int c) {
-  const int nv = c >> 2;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)n * nv) return;
-  const int img = idx / nv, j = idx % nv;
-  reinterpret_cast<float4*>(y)[idx] = load4<TX>(x + (size_t)img * L * c, j);
-}
-
 // ---- im2col -----------------------------------------------------------------------------
 template <typename TIN>
 __device__ __forceinline__ float load_px(const TIN* p) {
@@ -539,21 +530,6 @@ hipError_t launch_embed_ln_pre(void* x, int x_dtype, const float* cls, const flo
   else if (x_dtype == DT_BF16)
     hipLaunchKernelGGL(embed_ln_pre_kernel<bf16_t>, g, b, 0, s, reinterpret_cast<bf16_t*>(x), cls,
                        pos, gamma, beta, rows, L, c, reinterpret_cast<float2*>(rowpart));
-  else
-    return hipErrorInvalidValue;
-  return hipGetLastError();
-}
-
-hipError_t launch_copy_cls(const void* x, int x_dtype, float* y, int n, int L, int c, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  const long total = (long)n * (c >> 2);
-  const dim3 g((total + 255) / 256), b(256);
-  if (x_dtype == DT_F32)
-    hipLaunchKernelGGL(copy_cls_kernel<float>, g, b, 0, s, reinterpret_cast<const float*>(x), y, n, L, c);
-  else if (x_dtype == DT_F16)
-    hipLaunchKernelGGL(copy_cls_kernel<f16_t>, g, b, 0, s, reinterpret_cast<const f16_t*>(x), y, n, L, c);
-  else if (x_dtype == DT_BF16)
-    hipLaunchKernelGGL(copy_cls_kernel<bf16_t>, g, b, 0, s, reinterpret_cast<const bf16_t*>(x), y, n, L, c);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
