@@ -97,6 +97,32 @@ class COCODataset(BaseDataset[Batch]):
         mask = ~(inside_y[:, None] & inside_x[None, :])
         return F.interpolate(mask[None, None].float(), size=(self._grid, self._grid), mode='nearest')
 
+    def _masks(self, foregrounds: torch.Tensor, objects: torch.Tensor) -> torch.Tensor:
+        """``torch.cat([self._mask(fg, box) ...])`` for all proposals of an image at once.  'nearest'
+        resampling is separable, so a mask is the outer product of 14 column tests and 14 row tests at
+        the source indices torch picks (upsample_nearest: ``min(floor(dst * float(in) / out), in - 1)``,
+        float32) — no per-proposal pixel masks.  Bit-identical to the per-proposal path
+        (tests/test_pipeline_cpu.py), which cost 0.8 ms per proposal: 0.25 s per image of 300."""
+        import numpy as np
+        n, g = foregrounds.shape[0], self._grid
+        if n == 0:
+            return torch.zeros(0, 1, g, g)
+        fg = foregrounds.to(torch.float32).numpy()
+        box = objects.to(torch.float32).numpy().astype(np.float64)
+        out = np.empty((n, 1, g, g), np.float32)
+        dst = np.arange(g, dtype=np.float32)
+        inside = []
+        for lo, hi, a, b in ((0, 2, 0, 2), (1, 3, 1, 3)):
+            length = np.ceil(box[:, hi] - box[:, lo]).astype(np.int64)  # len(torch.arange(x2 - x1))
+            if (length < 1).any():
+                raise ValueError('empty object box')
+            scale = (length.astype(np.float32) / np.float32(g))[:, None]
+            src = np.minimum(np.floor(dst[None, :] * scale).astype(np.int64), (length - 1)[:, None])
+            src = src.astype(np.float32)
+            inside.append((fg[:, a, None] <= src) & (src <= fg[:, b, None]))
+        out[:, 0] = ~(inside[1][:, :, None] & inside[0][:, None, :])
+        return torch.from_numpy(out)
+
     def _preprocess(self, id_: int, output: pathlib.Path, image: PIL.Image.Image) -> Batch:
         prop = self._proposals[id_]
         proposals, objectness = prop[:, :4], prop[:, 4:]
@@ -111,19 +137,14 @@ class COCODataset(BaseDataset[Batch]):
         if self._device_preprocess:
             # masks (index math) here; the crops are cut + resized on the GPU from the uint8 image.
             # `objects` carries the image, `crop_boxes` the expanded boxes (PIL crop semantics).
-            masks = [self._mask(tuple(fg), tuple(box))
-                     for fg, box in zip(foregrounds.tolist(), bboxes.tolist())]
-            masks_t = torch.cat(masks) if masks else torch.zeros(0, 1, self._grid, self._grid)
-            return Batch(output, image_to_u8(image), proposals, objectness, masks_t, bboxes)
-        objects, masks = [], []
-        for fg, box in zip(foregrounds.tolist(), bboxes.tolist()):
-            objects.append(self._object(image, box))
-            masks.append(self._mask(tuple(fg), tuple(box)))
+            return Batch(output, image_to_u8(image), proposals, objectness,
+                         self._masks(foregrounds, bboxes), bboxes)
+        objects = [self._object(image, box) for box in bboxes.tolist()]
+        masks = self._masks(foregrounds, bboxes)
         if not objects:
             s = self.transform.n_px if hasattr(self.transform, 'n_px') else 224
-            return Batch(output, torch.zeros(0, 3, s, s), proposals, objectness,
-                         torch.zeros(0, 1, self._grid, self._grid))
-        return Batch(output, torch.stack(objects), proposals, objectness, torch.cat(masks))
+            return Batch(output, torch.zeros(0, 3, s, s), proposals, objectness, masks)
+        return Batch(output, torch.stack(objects), proposals, objectness, masks)
 
 
 class LVISDataset(COCODataset):

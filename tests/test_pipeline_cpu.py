@@ -233,3 +233,27 @@ def test_vild_prompt_tokenisation():
     assert (tok.argmax(dim=-1) == torch.tensor([6, 2])).all()
     with pytest.raises(ValueError):
         vild.adaptively_tokenize(['w ' * 80], enc)
+
+
+def test_objects_masks_vectorised_equals_per_proposal():
+    """COCODataset._masks (all proposals of an image at once) == torch.cat of the reference-shaped
+    per-proposal _mask, bit for bit, over fractional / degenerate-ish / out-of-crop boxes."""
+    ds = objects.COCODataset.__new__(objects.COCODataset)
+    ds._grid = 14
+    g = torch.Generator().manual_seed(3)
+    n = 600
+    x1 = torch.rand(n, generator=g) * 500
+    y1 = torch.rand(n, generator=g) * 400
+    w = torch.rand(n, generator=g) * 300 + 0.6
+    h = torch.rand(n, generator=g) * 300 + 0.6
+    boxes = torch.stack([x1, y1, x1 + w, y1 + h], 1)
+    boxes[:50] = boxes[:50].round()                       # integer sizes incl. exact multiples of the grid
+    boxes[50:60, 2] = boxes[50:60, 0] + 14.0
+    boxes[60:70, 3] = boxes[60:70, 1] + 28.0
+    fx1 = torch.rand(n, generator=g) * w * 0.8 - 5
+    fy1 = torch.rand(n, generator=g) * h * 0.8 - 5
+    fg = torch.stack([fx1, fy1, fx1 + torch.rand(n, generator=g) * w, fy1 + torch.rand(n, generator=g) * h], 1)
+    want = torch.cat([ds._mask(tuple(f), tuple(b)) for f, b in zip(fg.tolist(), boxes.tolist())])
+    got = ds._masks(fg, boxes)
+    assert got.shape == want.shape == (n, 1, 14, 14) and got.dtype == want.dtype
+    assert torch.equal(got, want)
