@@ -108,6 +108,12 @@ struct oake_handle {
   int32_t* rs_bounds = nullptr;
   uint8_t* rs_temp = nullptr;
   size_t rs_jobs_cap = 0, rs_coef_cap = 0, rs_bounds_cap = 0, rs_temp_cap = 0;
+  // pinned staging ring for the job descriptors: the upload needs no host-side wait for the stream
+  static constexpr int kJobRing = 8;
+  ResampleJob* rs_stage[kJobRing] = {};
+  size_t rs_stage_cap[kJobRing] = {};
+  hipEvent_t rs_stage_done[kJobRing] = {};
+  int rs_stage_next = 0;
 
   // JPEG decode scratch (grown on demand): pinned host coefficients, device coefficients + planes
   int16_t* jp_host = nullptr;
@@ -279,6 +285,10 @@ void oake_destroy(oake_handle* h) {
                   l.in_cs, l.fc_cs, l.in_bf, l.fc_bf};
     for (void* p : lp)
       if (p) (void)hipFree(p);
+  }
+  for (int i = 0; i < oake_handle::kJobRing; ++i) {
+    if (h->rs_stage[i]) (void)hipHostFree(h->rs_stage[i]);
+    if (h->rs_stage_done[i]) (void)hipEventDestroy(h->rs_stage_done[i]);
   }
   if (h->jp_host) (void)hipHostFree(h->jp_host);
   if (h->jp_copied) (void)hipEventDestroy(h->jp_copied);
@@ -767,9 +777,27 @@ int run_resample(oake_handle* h, hipStream_t s, const uint8_t* d_img, int height
   if ((rc = grow(h, s, &h->rs_coef, &h->rs_coef_cap, (size_t)coef * 4))) return rc;
   if ((rc = grow(h, s, &h->rs_bounds, &h->rs_bounds_cap, (size_t)bnd * 4))) return rc;
   if ((rc = grow(h, s, &h->rs_temp, &h->rs_temp_cap, (size_t)temp))) return rc;
-  HIP_TRY(h, hipMemcpyAsync(h->rs_jobs, jobs.data(), jobs.size() * sizeof(ResampleJob),
-                            hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipStreamSynchronize(s));  // `jobs` is a host temporary
+  // descriptors -> a pinned ring slot -> device, asynchronously (a wait only if the slot's previous
+  // upload, 8 calls ago, has not executed yet)
+  {
+    const int slot = h->rs_stage_next;
+    h->rs_stage_next = (slot + 1) % oake_handle::kJobRing;
+    const size_t need = jobs.size() * sizeof(ResampleJob);
+    if (!h->rs_stage_done[slot])
+      HIP_TRY(h, hipEventCreateWithFlags(&h->rs_stage_done[slot], hipEventDisableTiming));
+    else
+      HIP_TRY(h, hipEventSynchronize(h->rs_stage_done[slot]));
+    if (need > h->rs_stage_cap[slot]) {
+      if (h->rs_stage[slot]) HIP_TRY(h, hipHostFree(h->rs_stage[slot]));
+      h->rs_stage[slot] = nullptr;
+      h->rs_stage_cap[slot] = 0;
+      HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->rs_stage[slot]), need * 2, hipHostMallocDefault));
+      h->rs_stage_cap[slot] = need * 2;
+    }
+    std::memcpy(h->rs_stage[slot], jobs.data(), need);
+    HIP_TRY(h, hipMemcpyAsync(h->rs_jobs, h->rs_stage[slot], need, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipEventRecord(h->rs_stage_done[slot], s));
+  }
   const double bytes = (double)temp * 2 + (double)jobs.size() * out_size * out_size * 3 * 4;
   RUN(h, s, "resample", 0.0, bytes,
       launch_resample(d_img, height, width, h->rs_jobs, (int)jobs.size(), max_out, (int)max_ch_rw,
