@@ -258,7 +258,8 @@ class BaseValidator(ABC, Generic[T]):
 
     def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
                  batch_size: int = 256, device: torch.device | str | None = None,
-                 writer_threads: int = 4, decode_threads: int = 16, **kwargs) -> None:
+                 writer_threads: int = 4, decode_threads: int = 16, prefetch: int = 512,
+                 **kwargs) -> None:
         self.name = name
         self._model = model
         self._log_interval = (log or {}).get('interval', 50)
@@ -269,6 +270,7 @@ class BaseValidator(ABC, Generic[T]):
         self.counters = Counters()
         self._writer_threads = writer_threads
         self._decode_threads = decode_threads
+        self._prefetch = prefetch
         self._writer: AsyncWriter | None = None
         self._dataloader = self._build_dataloader(Config(dataloader))
 
@@ -342,8 +344,48 @@ class BaseValidator(ABC, Generic[T]):
         self.counters.seconds += time.perf_counter() - t0
         return self.counters
 
+    def _items(self):
+        """The dataloader's items, produced one flush ahead by a background thread when there are no
+        DataLoader workers: file reads and the per-image index math then overlap the encoder pass the
+        main thread is waiting on (both release the GIL for most of their time)."""
+        if getattr(self._dataloader, 'num_workers', 0) > 0 or self._prefetch <= 0:
+            yield from self._dataloader
+            return
+        q: queue.Queue = queue.Queue(maxsize=self._prefetch)
+        stop = threading.Event()
+        end = object()
+
+        def produce() -> None:
+            try:
+                for item in self._dataloader:
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(end)
+            except BaseException as e:  # noqa: BLE001 — re-raised in the consumer
+                q.put(e)
+
+        t = threading.Thread(target=produce, name='oake-prefetch', daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is end:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            t.join(timeout=5)
+
     def _run_loop(self, pending: list[T], crops: int) -> None:
-        for i, batch in enumerate(self._dataloader):
+        for i, batch in enumerate(self._items()):
             if batch is None:  # reference _control_run_iter: CONTINUE on None (base.py:96-104)
                 continue
             pending.append(batch)
