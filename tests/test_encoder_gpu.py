@@ -145,6 +145,41 @@ def test_encode_objects_vit_b32(cuda, resid32):
     _check(out, ref, 1e-3, 1e-3)
 
 
+def test_encode_objects_vit_b32_production_kernels(cuda):
+    """Objects mode where the work is big enough for the production path: 8 crops x 197 tokens = 1576
+    rows (+8 object-token rows in the same matrices) run the persistent LN-folded GEMMs with the row
+    statistics handed over, the cooperative attention kernel carries the object tokens on its idle
+    wave; the second pass (4 crops) takes the small-problem kernels.  Both against the oracle."""
+    sd = synthetic_state_dict()
+    model, sd2, cfg = _objects_model(sd, {}, max_batch=8)
+    x = synthetic_images(12, seed=31)
+    g = torch.Generator().manual_seed(12)
+    masks = (torch.rand(12, 1, 14, 14, generator=g) > 0.5).float()
+    masks[3] = 0
+    masks[7] = 1
+    ref = l2_normalize(encode_objects_ref(sd2, cfg, x, masks))
+    out = model.visual(x.to(cuda), masks.to(cuda), normalize=True, out_dtype=torch.float32)
+    _check(out, ref, 1e-3, 1e-3)
+
+
+def test_encode_objects_full_size_properties(cuda):
+    """BASELINE.json configs[3] at its size (600 crops = 2 images x 300 proposals, mini-batch 512):
+    splitting or permuting the crops must not change any crop's feature bit-wise."""
+    sd = synthetic_state_dict()
+    model, _, _ = _objects_model(sd, {}, max_batch=512)
+    x = synthetic_images(600, seed=8).half().to(cuda)
+    g = torch.Generator().manual_seed(600)
+    masks = (torch.rand(600, 1, 14, 14, generator=g) > 0.5).half().to(cuda)
+    full = model.visual(x, masks, normalize=True, out_dtype=torch.float16)
+    assert full.shape == (600, 512) and torch.isfinite(full.float()).all()
+    assert (full.float().norm(dim=1) - 1).abs().max().item() < 2e-3
+    halves = torch.cat([model.visual(x[:300], masks[:300], normalize=True, out_dtype=torch.float16),
+                        model.visual(x[300:], masks[300:], normalize=True, out_dtype=torch.float16)])
+    assert torch.equal(full, halves)
+    perm = torch.randperm(600, generator=torch.Generator().manual_seed(6)).to(cuda)
+    assert torch.equal(model.visual(x[perm], masks[perm], normalize=True, out_dtype=torch.float16), full[perm])
+
+
 def test_errors_are_loud(cuda):
     sd = synthetic_state_dict(**TINY)
     model, _ = clip.load(sd)
