@@ -201,8 +201,9 @@ OAKE_API int oake_encode_text(oake_handle* h, const int32_t* d_tokens, int n, in
  * PIL.Image.open(...).convert('RGB') (libjpeg-turbo defaults: islow IDCT, fancy upsampling) — the
  * decode of torchvision CocoDetection._load_image behind oadp/oake/base.py:53.  The Huffman pass runs
  * on the calling host thread, IDCT / upsampling / colour conversion on `stream`.  h_data is a HOST
- * buffer holding the whole file.  Progressive / arithmetic / CMYK / 12-bit files return
- * OAKE_ERR_UNSUPPORTED (decode those with PIL and upload the pixels instead).
+  * buffer holding the whole file.  Sequential and progressive Huffman-coded frames are covered;
+ * arithmetic-coded / CMYK / 12-bit files return OAKE_ERR_UNSUPPORTED (decode those with PIL and upload
+ * the pixels instead).
  * oake_jpeg_info needs no handle and no GPU.
  */
 OAKE_API int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width, int* components);

@@ -8,8 +8,9 @@
 //   jpeg_idct_kernel    dequantise + jpeg_idct_islow (jidctint.c, 13-bit fixed point, two passes)
 //   jpeg_rgb_kernel     "fancy" triangle-filter chroma upsampling (jdsample.c h2v1 / h2v2 / h1v2)
 //                       fused with the fixed-point YCbCr -> RGB of jdcolor.c, HWC uint8 out
-// Scope: 8-bit baseline sequential (SOF0/SOF1), 1 or 3 components in one interleaved scan, sampling
-// factors 1 or 2, restart intervals.  Anything else returns JPEG_UNSUPPORTED (the caller decides;
+// Scope: 8-bit Huffman-coded DCT frames — baseline / extended sequential (SOF0/SOF1, one interleaved
+// scan) and progressive (SOF2, any scan script) — 1 or 3 components, sampling factors 1 or 2, restart
+// intervals.  Anything else returns JPEG_UNSUPPORTED (the caller decides;
 // there is no silent CPU path).  The CPU restatement these kernels are tested against is
 // oracle/jpeg_ref.py, itself pinned bit-exactly to the Pillow in the image.
 #include <string.h>
@@ -167,7 +168,7 @@ int parse_markers(const uint8_t* d, size_t n, JpegFrame* f, Tables* t, std::stri
     if (pos >= n) return fail(JPEG_INVALID, "truncated before SOS");
     const uint8_t m = d[pos++];
     if (m == 0xD9) return fail(JPEG_INVALID, "EOI before SOS");
-    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (m == 0x00 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
     if (pos + 2 > n) return fail(JPEG_INVALID, "truncated segment");
     const int seg = be16(d + pos);
     if (seg < 2 || pos + seg > n) return fail(JPEG_INVALID, "bad segment length");
@@ -185,8 +186,9 @@ int parse_markers(const uint8_t* d, size_t n, JpegFrame* f, Tables* t, std::stri
         i += pq ? 128 : 64;
         have_q[tq] = true;
       }
-    } else if (m == 0xC0 || m == 0xC1) {
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
       if (len < 6 || b[0] != 8) return fail(JPEG_UNSUPPORTED, "only 8-bit samples");
+      f->progressive = m == 0xC2;
       f->height = be16(b + 1);
       f->width = be16(b + 3);
       f->ncomp = b[5];
@@ -200,9 +202,9 @@ int parse_markers(const uint8_t* d, size_t n, JpegFrame* f, Tables* t, std::stri
         if (comp_tq[c] > 3) return fail(JPEG_INVALID, "bad quantisation table index");
       }
       have_sof = true;
-    } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) ||
+    } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) ||
                (m >= 0xCD && m <= 0xCF)) {
-      return fail(JPEG_UNSUPPORTED, "only baseline sequential Huffman JPEG (progressive/arithmetic/lossless not supported)");
+      return fail(JPEG_UNSUPPORTED, "only Huffman-coded sequential / progressive DCT JPEG (arithmetic, lossless, hierarchical not supported)");
     } else if (m == 0xC4) {
       int i = 0;
       while (i < len) {
@@ -220,6 +222,7 @@ int parse_markers(const uint8_t* d, size_t n, JpegFrame* f, Tables* t, std::stri
       if (t) t->restart_interval = be16(b);
     } else if (m == 0xDA) {
       if (!have_sof) return fail(JPEG_INVALID, "SOS before SOF");
+      if (f->progressive) break;  // scans are walked by decode_progressive
       if (len < 1 || b[0] != f->ncomp || len < 1 + 2 * f->ncomp)
         return fail(JPEG_UNSUPPORTED, "only single interleaved scans");
       for (int k = 0; k < f->ncomp; ++k) {
@@ -238,6 +241,7 @@ int parse_markers(const uint8_t* d, size_t n, JpegFrame* f, Tables* t, std::stri
     }
     pos += seg;
   }
+  for (int c = 0; c < 3; ++c) f->comp_id[c] = comp_id[c];
   if (f->width <= 0 || f->height <= 0) return fail(JPEG_INVALID, "empty image");
   if (f->ncomp == 1) f->h[0] = f->v[0] = 1;  // a single-component scan is not interleaved
   f->hmax = f->vmax = 1;
@@ -267,6 +271,218 @@ int parse_markers(const uint8_t* d, size_t n, JpegFrame* f, Tables* t, std::stri
   return JPEG_OK;
 }
 
+// ---- progressive frames (ITU T.81 Annex G, jdphuff.c) ------------------------------------------
+// One scan: DC first / DC refinement (possibly interleaved) or AC first / AC refinement (one
+// component, over that component's own blocks, not the MCU-padded ones).
+int decode_progressive_scan(BitReader& br, const JpegFrame& fr, const Tables& t, const int* scan_ci, int ns,
+                            int ss, int se, int ah, int al, int16_t* coefs, std::string* err) {
+  auto fail = [&](const char* m) {
+    if (err) *err = m;
+    return JPEG_INVALID;
+  };
+  if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) return fail("bad progressive scan header");
+  int pred[3] = {0, 0, 0};
+  int eobrun = 0;
+  int ux_n, uy_n;
+  if (ns > 1) {
+    ux_n = fr.mcux;
+    uy_n = fr.mcuy;
+  } else {
+    const int c = scan_ci[0];
+    ux_n = ((fr.width * fr.h[c] + fr.hmax - 1) / fr.hmax + 7) / 8;
+    uy_n = ((fr.height * fr.v[c] + fr.vmax - 1) / fr.vmax + 7) / 8;
+  }
+  const int p1 = 1 << al, m1 = -(1 << al);
+  long count = 0;
+  for (int uy = 0; uy < uy_n; ++uy) {
+    for (int ux = 0; ux < ux_n; ++ux) {
+      if (t.restart_interval && count && count % t.restart_interval == 0) {
+        if (!br.restart()) return fail("missing restart marker");
+        pred[0] = pred[1] = pred[2] = 0;
+        eobrun = 0;
+      }
+      ++count;
+      for (int sc = 0; sc < ns; ++sc) {
+        const int c = scan_ci[sc];
+        const int nby = ns > 1 ? fr.v[c] : 1, nbx = ns > 1 ? fr.h[c] : 1;
+        for (int by = 0; by < nby; ++by) {
+          for (int bx = 0; bx < nbx; ++bx) {
+            const long brow = ns > 1 ? (long)uy * fr.v[c] + by : uy;
+            const long bcol = ns > 1 ? (long)ux * fr.h[c] + bx : ux;
+            int16_t* blk = coefs + fr.coef_off[c] + (brow * fr.bx[c] + bcol) * 64;
+            if (ss == 0) {
+              if (ah == 0) {
+                const int s = br.decode(t.dc[t.td[c]]);
+                if (s < 0 || s > 15) return fail("corrupt DC code");
+                if (s) pred[c] += br.receive_extend(s);
+                blk[0] = (int16_t)(pred[c] * (1 << al));
+              } else {
+                if (br.cnt < 1) br.fill();
+                if (br.peek(1)) blk[0] = (int16_t)(blk[0] | p1);
+                br.drop(1);
+              }
+              continue;
+            }
+            const Huff& ha = t.ac[t.ta[c]];
+            if (ah == 0) {  // AC first
+              if (eobrun) {
+                --eobrun;
+                continue;
+              }
+              for (int k = ss; k <= se;) {
+                const int rs = br.decode(ha);
+                if (rs < 0) return fail("corrupt AC code");
+                const int r = rs >> 4, s = rs & 15;
+                if (s == 0) {
+                  if (r == 15) {
+                    k += 16;
+                    continue;
+                  }
+                  eobrun = (1 << r) - 1;
+                  if (r) {
+                    if (br.cnt < r) br.fill();
+                    eobrun += (int)br.peek(r);
+                    br.drop(r);
+                  }
+                  break;
+                }
+                k += r;
+                if (k > se) return fail("AC run past the band");
+                blk[kZigzag[k]] = (int16_t)(br.receive_extend(s) * (1 << al));
+                ++k;
+              }
+              continue;
+            }
+            // AC refinement
+            int k = ss;
+            if (eobrun == 0) {
+              while (k <= se) {
+                const int rs = br.decode(ha);
+                if (rs < 0) return fail("corrupt AC code");
+                int r = rs >> 4;
+                const int s = rs & 15;
+                int val = 0;
+                if (s) {
+                  if (s != 1) return fail("corrupt AC refinement");
+                  if (br.cnt < 1) br.fill();
+                  val = br.peek(1) ? p1 : m1;
+                  br.drop(1);
+                } else if (r != 15) {
+                  eobrun = 1 << r;
+                  if (r) {
+                    if (br.cnt < r) br.fill();
+                    eobrun += (int)br.peek(r);
+                    br.drop(r);
+                  }
+                  break;
+                }
+                while (k <= se) {
+                  int16_t& cz = blk[kZigzag[k]];
+                  if (cz != 0) {
+                    if (br.cnt < 1) br.fill();
+                    if (br.peek(1) && (cz & p1) == 0) cz = (int16_t)(cz + (cz >= 0 ? p1 : m1));
+                    br.drop(1);
+                  } else {
+                    if (r == 0) {
+                      if (val) cz = (int16_t)val;
+                      ++k;
+                      break;
+                    }
+                    --r;
+                  }
+                  ++k;
+                }
+              }
+            }
+            if (eobrun > 0) {
+              for (; k <= se; ++k) {
+                int16_t& cz = blk[kZigzag[k]];
+                if (cz != 0) {
+                  if (br.cnt < 1) br.fill();
+                  if (br.peek(1) && (cz & p1) == 0) cz = (int16_t)(cz + (cz >= 0 ? p1 : m1));
+                  br.drop(1);
+                }
+              }
+              --eobrun;
+            }
+          }
+        }
+      }
+    }
+  }
+  return JPEG_OK;
+}
+
+// All scans of a progressive file: tables may change between scans.
+int decode_progressive(const uint8_t* d, size_t n, const JpegFrame& fr, int16_t* coefs, std::string* err) {
+  auto fail = [&](int rc, const char* m) {
+    if (err) *err = m;
+    return rc;
+  };
+  Tables t;
+  size_t pos = 2;
+  int scans = 0;
+  for (;;) {
+    while (pos < n && d[pos] != 0xFF) ++pos;
+    while (pos < n && d[pos] == 0xFF) ++pos;
+    if (pos >= n) break;
+    const uint8_t m = d[pos++];
+    if (m == 0xD9) break;
+    if (m == 0x00 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (pos + 2 > n) return fail(JPEG_INVALID, "truncated segment");
+    const int seg = be16(d + pos);
+    if (seg < 2 || pos + seg > n) return fail(JPEG_INVALID, "bad segment length");
+    const uint8_t* b = d + pos + 2;
+    const int len = seg - 2;
+    if (m == 0xC4) {
+      int i = 0;
+      while (i < len) {
+        if (i + 17 > len) return fail(JPEG_INVALID, "bad DHT");
+        const int tc = b[i] >> 4, th = b[i] & 15;
+        int cnt = 0;
+        for (int k = 0; k < 16; ++k) cnt += b[i + 1 + k];
+        if (th > 3 || tc > 1 || cnt > 256 || i + 17 + cnt > len) return fail(JPEG_INVALID, "bad DHT");
+        if (!(tc ? t.ac[th] : t.dc[th]).build(b + i + 1, b + i + 17, cnt))
+          return fail(JPEG_INVALID, "bad DHT (oversubscribed code lengths)");
+        i += 17 + cnt;
+      }
+    } else if (m == 0xDD) {
+      if (len < 2) return fail(JPEG_INVALID, "bad DRI");
+      t.restart_interval = be16(b);
+    } else if (m == 0xDA) {
+      if (len < 1) return fail(JPEG_INVALID, "bad SOS");
+      const int ns = b[0];
+      if (ns < 1 || ns > fr.ncomp || len < 4 + 2 * ns) return fail(JPEG_INVALID, "bad SOS");
+      int scan_ci[3];
+      for (int k = 0; k < ns; ++k) {
+        int c = -1;
+        for (int j = 0; j < fr.ncomp; ++j)
+          if (fr.comp_id[j] == b[1 + 2 * k]) c = j;
+        if (c < 0) return fail(JPEG_INVALID, "scan names an unknown component");
+        scan_ci[k] = c;
+        t.td[c] = b[2 + 2 * k] >> 4;
+        t.ta[c] = b[2 + 2 * k] & 15;
+        if (t.td[c] > 3 || t.ta[c] > 3) return fail(JPEG_INVALID, "bad Huffman table index");
+      }
+      const int ss = b[1 + 2 * ns], se = b[2 + 2 * ns], ah = b[3 + 2 * ns] >> 4, al = b[3 + 2 * ns] & 15;
+      for (int k = 0; k < ns; ++k) {
+        const int c = scan_ci[k];
+        if (ss == 0 && ah == 0 && !t.dc[t.td[c]].present) return fail(JPEG_INVALID, "missing Huffman table");
+        if (ss > 0 && !t.ac[t.ta[c]].present) return fail(JPEG_INVALID, "missing Huffman table");
+      }
+      BitReader br{d, n, pos + (size_t)seg};
+      const int rc = decode_progressive_scan(br, fr, t, scan_ci, ns, ss, se, ah, al, coefs, err);
+      if (rc != JPEG_OK) return rc;
+      ++scans;
+      pos = br.pos;  // the reader stops in front of the next marker
+      continue;
+    }
+    pos += seg;
+  }
+  if (!scans) return fail(JPEG_INVALID, "no scan found");
+  return JPEG_OK;
+}
+
 }  // namespace
 
 int jpeg_read_frame(const uint8_t* data, size_t n, JpegFrame* frame, std::string* err) {
@@ -275,6 +491,8 @@ int jpeg_read_frame(const uint8_t* data, size_t n, JpegFrame* frame, std::string
 
 int jpeg_decode_coefs(const uint8_t* data, size_t n, const JpegFrame& fr, int16_t* coefs,
                       std::string* err) {
+  memset(coefs, 0, (size_t)fr.total_coefs * sizeof(int16_t));
+  if (fr.progressive) return decode_progressive(data, n, fr, coefs, err);
   JpegFrame f2;
   Tables t;
   int rc = parse_markers(data, n, &f2, &t, err);
@@ -284,7 +502,6 @@ int jpeg_decode_coefs(const uint8_t* data, size_t n, const JpegFrame& fr, int16_
       if (err) *err = "missing Huffman table";
       return JPEG_INVALID;
     }
-  memset(coefs, 0, (size_t)fr.total_coefs * sizeof(int16_t));
   BitReader br{data, n, t.scan_pos};
   int pred[3] = {0, 0, 0};
   long count = 0;

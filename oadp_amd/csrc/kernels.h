@@ -142,6 +142,8 @@ hipError_t launch_resample(const uint8_t* img, int height, int width, const Resa
 enum { JPEG_OK = 0, JPEG_INVALID = 1, JPEG_UNSUPPORTED = 2 };
 struct JpegFrame {
   int width, height, ncomp, hmax, vmax, mcux, mcuy;
+  int progressive;           // SOF2: coefficients arrive over several scans
+  int comp_id[3];            // component identifiers of the frame header (scan headers refer to them)
   int h[3], v[3];            // sampling factors
   int bx[3], by[3];          // blocks per row / column of each (MCU-padded) component plane
   long coef_off[3];          // int16 element offset of each component's [by][bx][64] coefficients

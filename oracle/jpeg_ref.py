@@ -8,7 +8,8 @@ YCbCr -> RGB tables of jdcolor.c.  libjpeg-turbo is a third-party dependency tha
 /root/reference; this file restates its published algorithm in numpy (slow: pure-Python Huffman loop,
 small images only) and is pinned BIT-EXACTLY against the Pillow 12.2 / libjpeg-turbo build in this
 image by tests/test_jpeg.py.  Scope: 8-bit baseline sequential DCT (SOF0/SOF1 Huffman), 1 or 3
-components, sampling factors 1 or 2, restart intervals.  Progressive / arithmetic / CMYK: NotImplementedError.
+components, sampling factors 1 or 2, restart intervals; progressive frames (SOF2, jdphuff.c) behind
+``progressive_ok``.  Arithmetic coding / CMYK / 12-bit: NotImplementedError.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -99,84 +100,7 @@ def _extend(v: int, s: int) -> int:
     return v if v >= (1 << (s - 1)) else v - (1 << s) + 1
 
 
-def parse(data: bytes):
-    """-> (height, width, components, qtables[4] (natural order), coefficient planes per component
-    [blocks_y, blocks_x, 64] int32 in natural order, already multiplied by nothing (raw))."""
-    assert data[0:2] == b'\xff\xd8', 'not a JPEG'
-    pos = 2
-    qt: dict[int, np.ndarray] = {}
-    dc: dict[int, HuffTable] = {}
-    ac: dict[int, HuffTable] = {}
-    comps: list[Component] = []
-    height = width = 0
-    ri = 0
-    while True:
-        while data[pos] != 0xFF:
-            pos += 1
-        while data[pos] == 0xFF:
-            pos += 1
-        m = data[pos]
-        pos += 1
-        if m == 0xD9:
-            raise ValueError('EOI before SOS')
-        if m in (0x01,) or 0xD0 <= m <= 0xD7:
-            continue
-        (seg,) = struct.unpack('>H', data[pos:pos + 2])
-        body = data[pos + 2:pos + seg]
-        if m == 0xDB:
-            i = 0
-            while i < len(body):
-                pq, tq = body[i] >> 4, body[i] & 15
-                i += 1
-                if pq:
-                    vals = np.frombuffer(body[i:i + 128], dtype='>u2').astype(np.int64)
-                    i += 128
-                else:
-                    vals = np.frombuffer(body[i:i + 64], dtype=np.uint8).astype(np.int64)
-                    i += 64
-                nat = np.zeros(64, np.int64)
-                nat[ZIGZAG] = vals
-                qt[tq] = nat
-        elif m in (0xC0, 0xC1):
-            assert body[0] == 8, 'only 8-bit samples'
-            height, width = struct.unpack('>HH', body[1:5])
-            for c in range(body[5]):
-                cid, hv, tq = body[6 + 3 * c:9 + 3 * c]
-                comps.append(Component(cid, hv >> 4, hv & 15, tq))
-        elif m in (0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
-            raise NotImplementedError(f'SOF marker {m:#x}: only baseline sequential Huffman JPEG')
-        elif m == 0xC4:
-            i = 0
-            while i < len(body):
-                tc, th = body[i] >> 4, body[i] & 15
-                bits = list(body[i + 1:i + 17])
-                n = sum(bits)
-                vals = list(body[i + 17:i + 17 + n])
-                (ac if tc else dc)[th] = HuffTable(bits, vals)
-                i += 17 + n
-        elif m == 0xDD:
-            (ri,) = struct.unpack('>H', body[0:2])
-        elif m == 0xDA:
-            ns = body[0]
-            assert ns == len(comps), 'non-interleaved scans are not supported'
-            for k in range(ns):
-                cs, tt = body[1 + 2 * k], body[2 + 2 * k]
-                comp = next(c for c in comps if c.cid == cs)
-                comp.td, comp.ta = tt >> 4, tt & 15
-            pos += seg
-            break
-        pos += seg
-
-    if len(comps) not in (1, 3):
-        raise NotImplementedError('only grayscale and YCbCr')
-    if len(comps) == 1:
-        comps[0].h = comps[0].v = 1  # a single-component scan is never interleaved
-    hmax = max(c.h for c in comps)
-    vmax = max(c.v for c in comps)
-    mcux = -(-width // (8 * hmax))
-    mcuy = -(-height // (8 * vmax))
-    planes = [np.zeros((mcuy * c.v, mcux * c.h, 64), np.int32) for c in comps]
-    br = BitReader(data, pos)
+def _decode_scan_baseline(br, comps, planes, dc, ac, mcux, mcuy, ri):
     count = 0
     for my in range(mcuy):
         for mx in range(mcux):
@@ -205,6 +129,197 @@ def parse(data: bytes):
                             k += r
                             blk[ZIGZAG[k]] = _extend(br.bits(s), s)
                             k += 1
+
+
+def _decode_scan_progressive(br, scan, comps, planes, dc, ac, width, height, hmax, vmax, ri, ss, se, ah, al):
+    """One scan of a progressive frame (ITU T.81 G.1.2 / jdphuff.c): DC first / refine (may be
+    interleaved), AC first / refine (always a single component, over that component's own blocks)."""
+    for c, _ in scan:
+        c.pred = 0
+    eobrun = 0
+    if len(scan) > 1:
+        mcux = -(-width // (8 * hmax))
+        mcuy = -(-height // (8 * vmax))
+        units = [(mx, my) for my in range(mcuy) for mx in range(mcux)]
+    else:
+        c = scan[0][0]
+        bw = -(-(-(-width * c.h // hmax)) // 8)   # ceil(ceil(W h / hmax) / 8): the component's own blocks
+        bh = -(-(-(-height * c.v // vmax)) // 8)
+        units = [(bx, by) for by in range(bh) for bx in range(bw)]
+    count = 0
+    for ux, uy in units:
+        if ri and count and count % ri == 0:
+            br.restart()
+            for c, _ in scan:
+                c.pred = 0
+            eobrun = 0
+        count += 1
+        if len(scan) > 1:
+            blocks = [(c, planes[ci][uy * c.v + by, ux * c.h + bx]) for c, ci in scan
+                      for by in range(c.v) for bx in range(c.h)]
+        else:
+            c, ci = scan[0]
+            blocks = [(c, planes[ci][uy, ux])]
+        for c, blk in blocks:
+            if ss == 0:
+                if ah == 0:
+                    s = br.decode(dc[c.td])
+                    c.pred += _extend(br.bits(s), s) if s else 0
+                    blk[0] = c.pred * (1 << al)
+                elif br.bit():
+                    blk[0] |= 1 << al
+                continue
+            if ah == 0:  # AC first
+                if eobrun:
+                    eobrun -= 1
+                    continue
+                k = ss
+                while k <= se:
+                    rs = br.decode(ac[c.ta])
+                    r, s = rs >> 4, rs & 15
+                    if s == 0:
+                        if r == 15:
+                            k += 16
+                            continue
+                        eobrun = (1 << r) - 1 + (br.bits(r) if r else 0)
+                        break
+                    k += r
+                    blk[ZIGZAG[k]] = _extend(br.bits(s), s) * (1 << al)
+                    k += 1
+                continue
+            # AC refinement
+            p1, m1 = 1 << al, -1 << al
+            k = ss
+            if eobrun == 0:
+                while k <= se:
+                    rs = br.decode(ac[c.ta])
+                    r, s = rs >> 4, rs & 15
+                    val = 0
+                    if s:
+                        val = p1 if br.bit() else m1
+                    elif r != 15:
+                        eobrun = (1 << r) + (br.bits(r) if r else 0)
+                        break
+                    while k <= se:
+                        z = ZIGZAG[k]
+                        if blk[z] != 0:
+                            if br.bit() and (blk[z] & p1) == 0:
+                                blk[z] += p1 if blk[z] >= 0 else m1
+                        else:
+                            if r == 0:
+                                if val:
+                                    blk[z] = val
+                                k += 1
+                                break
+                            r -= 1
+                        k += 1
+            if eobrun > 0:
+                while k <= se:
+                    z = ZIGZAG[k]
+                    if blk[z] != 0 and br.bit() and (blk[z] & p1) == 0:
+                        blk[z] += p1 if blk[z] >= 0 else m1
+                    k += 1
+                eobrun -= 1
+
+
+def parse(data: bytes, progressive_ok: bool = False):
+    """-> (height, width, components, qtables (natural order), coefficient planes per component
+    [blocks_y, blocks_x, 64] int32 in natural order (MCU-padded)).  Progressive frames (SOF2) only with
+    ``progressive_ok`` (the device decoder's host half implements them; see tests/test_jpeg.py)."""
+    assert data[0:2] == b'\xff\xd8', 'not a JPEG'
+    pos = 2
+    qt: dict[int, np.ndarray] = {}
+    dc: dict[int, HuffTable] = {}
+    ac: dict[int, HuffTable] = {}
+    comps: list[Component] = []
+    planes = None
+    height = width = 0
+    ri = 0
+    progressive = False
+    while True:
+        while pos < len(data) and data[pos] != 0xFF:
+            pos += 1
+        while pos < len(data) and data[pos] == 0xFF:
+            pos += 1
+        if pos >= len(data):
+            break
+        m = data[pos]
+        pos += 1
+        if m == 0xD9:
+            break
+        if m in (0x01,) or 0xD0 <= m <= 0xD7:
+            continue
+        (seg,) = struct.unpack('>H', data[pos:pos + 2])
+        body = data[pos + 2:pos + seg]
+        if m == 0xDB:
+            i = 0
+            while i < len(body):
+                pq, tq = body[i] >> 4, body[i] & 15
+                i += 1
+                if pq:
+                    vals = np.frombuffer(body[i:i + 128], dtype='>u2').astype(np.int64)
+                    i += 128
+                else:
+                    vals = np.frombuffer(body[i:i + 64], dtype=np.uint8).astype(np.int64)
+                    i += 64
+                nat = np.zeros(64, np.int64)
+                nat[ZIGZAG] = vals
+                qt[tq] = nat
+        elif m in (0xC0, 0xC1, 0xC2):
+            if m == 0xC2:
+                if not progressive_ok:
+                    raise NotImplementedError('SOF2: progressive JPEG')
+                progressive = True
+            assert body[0] == 8, 'only 8-bit samples'
+            height, width = struct.unpack('>HH', body[1:5])
+            for c in range(body[5]):
+                cid, hv, tq = body[6 + 3 * c:9 + 3 * c]
+                comps.append(Component(cid, hv >> 4, hv & 15, tq))
+            if len(comps) not in (1, 3):
+                raise NotImplementedError('only grayscale and YCbCr')
+            if len(comps) == 1:
+                comps[0].h = comps[0].v = 1  # a single-component scan is never interleaved
+            hmax = max(c.h for c in comps)
+            vmax = max(c.v for c in comps)
+            mcux = -(-width // (8 * hmax))
+            mcuy = -(-height // (8 * vmax))
+            planes = [np.zeros((mcuy * c.v, mcux * c.h, 64), np.int32) for c in comps]
+        elif m in (0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
+            raise NotImplementedError(f'SOF marker {m:#x}: only Huffman sequential / progressive DCT')
+        elif m == 0xC4:
+            i = 0
+            while i < len(body):
+                tc, th = body[i] >> 4, body[i] & 15
+                bits = list(body[i + 1:i + 17])
+                n = sum(bits)
+                vals = list(body[i + 17:i + 17 + n])
+                (ac if tc else dc)[th] = HuffTable(bits, vals)
+                i += 17 + n
+        elif m == 0xDD:
+            (ri,) = struct.unpack('>H', body[0:2])
+        elif m == 0xDA:
+            ns = body[0]
+            scan = []
+            for k in range(ns):
+                cs, tt = body[1 + 2 * k], body[2 + 2 * k]
+                ci = next(i for i, c in enumerate(comps) if c.cid == cs)
+                comps[ci].td, comps[ci].ta = tt >> 4, tt & 15
+                scan.append((comps[ci], ci))
+            ss, se, aa = body[1 + 2 * ns], body[2 + 2 * ns], body[3 + 2 * ns]
+            br = BitReader(data, pos + seg)
+            if not progressive:
+                assert ns == len(comps), 'non-interleaved sequential scans are not supported'
+                for c in comps:
+                    c.pred = 0
+                _decode_scan_baseline(br, comps, planes, dc, ac, mcux, mcuy, ri)
+                return height, width, comps, qt, planes
+            _decode_scan_progressive(br, scan, comps, planes, dc, ac, width, height, hmax, vmax, ri, ss, se,
+                                     aa >> 4, aa & 15)
+            pos = br.pos  # (the bit reader stops in front of the next marker)
+            continue
+        pos += seg
+    if planes is None or not progressive:
+        raise ValueError('no scan found')
     return height, width, comps, qt, planes
 
 
@@ -319,9 +434,9 @@ def ycc_to_rgb(y: np.ndarray, cb: np.ndarray, cr: np.ndarray) -> np.ndarray:
     return np.clip(np.stack([r, g, b], axis=-1), 0, 255).astype(np.uint8)
 
 
-def decode(data: bytes) -> np.ndarray:
+def decode(data: bytes, progressive_ok: bool = False) -> np.ndarray:
     """-> uint8 [H, W, 3], equal to np.asarray(PIL.Image.open(...).convert('RGB'))."""
-    height, width, comps, qt, planes = parse(data)
+    height, width, comps, qt, planes = parse(data, progressive_ok)
     hmax = max(c.h for c in comps)
     vmax = max(c.v for c in comps)
     full = []

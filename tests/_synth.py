@@ -26,14 +26,17 @@ def make_coco(root: pathlib.Path, sizes, proposals_per_image: int = 12, seed: in
         arr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
         name = f'{id_:012d}.{fmt}'
         if fmt == 'jpg':
-            # smooth content + varied JPEG flavours (4:2:0 / 4:2:2 / 4:4:4, optimised tables, restarts, one
-            # progressive file that the device decoder must hand back to PIL)
+            # smooth content + varied JPEG flavours (4:2:0 / 4:2:2 / 4:4:4, optimised tables, restarts,
+            # progressive, and one CMYK file that the device decoder must hand back to PIL)
             yy, xx = np.mgrid[0:h, 0:w]
             arr = (arr // 4 + np.stack([(xx * 3 + yy) % 192, (xx + yy * 2) % 192, (xx * yy) % 192], -1)).astype(np.uint8)
             k = len(images)
-            PIL.Image.fromarray(arr).save(img_dir / name, quality=(95, 80, 60)[k % 3], subsampling=(2, 1, 0)[k % 3],
-                                          optimize=k % 2 == 1, progressive=k == 2,
-                                          **(dict(restart_marker_blocks=7) if k == 3 else {}))
+            if k == 2:
+                PIL.Image.fromarray(arr).convert('CMYK').save(img_dir / name, quality=85)
+            else:
+                PIL.Image.fromarray(arr).save(img_dir / name, quality=(95, 80, 60)[k % 3], subsampling=(2, 1, 0)[k % 3],
+                                              optimize=k % 2 == 1, progressive=k in (1, 4),
+                                              **(dict(restart_marker_blocks=7) if k == 3 else {}))
         else:
             PIL.Image.fromarray(arr).save(img_dir / name)
         images.append(dict(id=id_, file_name=name, width=w, height=h,

@@ -53,10 +53,22 @@ def test_oracle_grayscale_optimized_restart():
     assert np.array_equal(jpeg_ref.decode(data), _pil(data))
 
 
-def test_oracle_rejects_progressive():
+def test_oracle_progressive():
     data = _encode(_synth(16, 16, 'grad'), quality=80, progressive=True)
     with pytest.raises(NotImplementedError):
-        jpeg_ref.decode(data)
+        jpeg_ref.decode(data)  # (opt-in: the baseline oracle stays the default)
+    for (h, w, ss, q, kind) in CASES[::4]:
+        data = _encode(_synth(h, w, kind), quality=q, subsampling=ss, progressive=True)
+        assert np.array_equal(jpeg_ref.decode(data, progressive_ok=True), _pil(data))
+    g = (np.random.default_rng(4).random((21, 35)) * 255).astype(np.uint8)
+    data = _encode(g, quality=80, progressive=True)
+    assert np.array_equal(jpeg_ref.decode(data, progressive_ok=True), _pil(data))
+
+
+def _cmyk(a, **kw):
+    b = io.BytesIO()
+    Image.fromarray(a).convert('CMYK').save(b, 'JPEG', **kw)
+    return b.getvalue()
 
 
 def _host_coefs(lib, data):
@@ -95,9 +107,15 @@ def test_host_huffman_restart_optimized_info():
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
         assert lib.oake_jpeg_info(buf, len(data), C.byref(hh), C.byref(ww), C.byref(cc)) == 0
         assert (hh.value, ww.value, cc.value) == (45, 70, 3)
-    prog = _encode(a, quality=80, progressive=True)
-    buf = (C.c_uint8 * len(prog)).from_buffer_copy(prog)
-    assert lib.oake_jpeg_info(buf, len(prog), None, None, None) == _lib.OAKE_ERR_UNSUPPORTED
+    for kw in (dict(quality=80, progressive=True), dict(quality=60, progressive=True, subsampling=2),
+               dict(quality=92, progressive=True, subsampling=0, optimize=True)):
+        data = _encode(a, **kw)  # progressive: several scans, spectral selection + successive approximation
+        _, _, _, _, planes = jpeg_ref.parse(data, progressive_ok=True)
+        ref = np.concatenate([p.reshape(-1) for p in planes]).astype(np.int16)
+        assert np.array_equal(_host_coefs(lib, data), ref)
+    cmyk = _cmyk(a, quality=80)
+    buf = (C.c_uint8 * len(cmyk)).from_buffer_copy(cmyk)
+    assert lib.oake_jpeg_info(buf, len(cmyk), None, None, None) == _lib.OAKE_ERR_UNSUPPORTED
     # fuzz: corrupted files must be rejected or decoded to *something*, never crash the process
     rng = np.random.default_rng(11)
     good = _encode(a, quality=85, subsampling=2)
@@ -149,7 +167,8 @@ def test_device_decode_batch(cuda):
     model, _ = clip.load(synthetic_state_dict(**TINY), max_batch=2)
     datas = [_encode(_synth(40 + 7 * i, 50 + 11 * i, 'grad' if i % 2 else 'noise', seed=i), quality=60 + 3 * i,
                      subsampling=i % 3) for i in range(12)]
-    datas.insert(5, _encode(_synth(32, 32, 'grad'), quality=80, progressive=True))  # unsupported -> None
+    datas.insert(3, _encode(_synth(61, 47, 'grad'), quality=80, progressive=True, subsampling=2))
+    datas.insert(5, _cmyk(_synth(32, 32, 'grad'), quality=80))  # unsupported -> None
     datas.insert(9, b'garbage')
     for threads in (1, 4, 32):
         outs = model.visual.decode_jpeg_batch(datas, threads=threads)
@@ -169,7 +188,10 @@ def test_device_decode_gray_restart_errors(cuda):
     for data in (_encode(g, quality=80), _encode(_synth(90, 130, 'noise'), quality=85, optimize=True),
                  _encode(_synth(90, 130, 'grad'), quality=70, subsampling=2, restart_marker_blocks=5)):
         assert np.array_equal(model.visual.decode_jpeg(data).cpu().numpy(), _pil(data))
+    for data in (_encode(_synth(90, 130, 'grad'), quality=80, progressive=True, subsampling=2),
+                 _encode(_synth(33, 70, 'noise'), quality=95, progressive=True, subsampling=0)):
+        assert np.array_equal(model.visual.decode_jpeg(data).cpu().numpy(), _pil(data))
     with pytest.raises(_lib.OakeError):
-        model.visual.decode_jpeg(_encode(_synth(32, 32, 'grad'), quality=80, progressive=True))
+        model.visual.decode_jpeg(_cmyk(_synth(32, 32, 'grad'), quality=80))
     with pytest.raises(_lib.OakeError):
         model.visual.decode_jpeg(b'not a jpeg at all')

@@ -145,7 +145,7 @@ def test_device_decode_matches_host_decode(cuda, tmp_path, monkeypatch):
                     assert torch.equal(a[k], b[k]), (tag, id_, k)
             else:
                 assert torch.equal(a, b), (tag, id_)
-    # 'strict' refuses the progressive file instead of handing it to PIL
+    # 'strict' refuses the CMYK file instead of handing it to PIL
     with pytest.raises(ValueError):
         model, pre = clip.load(sd, max_batch=64)
         dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 's'),

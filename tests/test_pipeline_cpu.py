@@ -213,7 +213,7 @@ def test_device_decode_dataset_hands_over_file_bytes(tmp_path):
             assert b.image.dtype == torch.uint8 and b.image.shape[2] == 3
             assert np.array_equal(b.image.numpy(), np.asarray(PIL.Image.open(tmp_path / 'coco' / 'images' / name).convert('RGB')))
             kinds.append('pixels')
-    assert kinds.count('pixels') == 1 and kinds.count('bytes') == 3  # one progressive file in the set
+    assert kinds.count('pixels') == 1 and kinds.count('bytes') == 3  # one CMYK file in the set
     strict = globals_.Dataset(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 'o2'),
                               transform=_synth.preprocess(), device_decode='strict')
     with pytest.raises(ValueError):
