@@ -118,8 +118,9 @@ def test_host_huffman_restart_optimized_info():
     assert lib.oake_jpeg_info(buf, len(cmyk), None, None, None) == _lib.OAKE_ERR_UNSUPPORTED
     # fuzz: corrupted files must be rejected or decoded to *something*, never crash the process
     rng = np.random.default_rng(11)
-    good = _encode(a, quality=85, subsampling=2)
-    for trial in range(300):
+    goods = [_encode(a, quality=85, subsampling=2), _encode(a, quality=75, subsampling=2, progressive=True)]
+    for trial in range(600):
+        good = goods[trial % 2]
         bad = bytearray(good)
         for _ in range(int(rng.integers(1, 6))):
             bad[int(rng.integers(2, len(bad)))] = int(rng.integers(0, 256))
