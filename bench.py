@@ -64,7 +64,8 @@ def main() -> None:
     dev = torch.device('cuda', local % torch.cuda.device_count())
     if dist:
         import torch.distributed as td
-        td.init_process_group(backend='nccl')  # RCCL on ROCm
+        # RCCL on ROCm; OAKE_BENCH_BACKEND=gloo lets two ranks share one GPU to exercise this path on a 1-GPU box
+        td.init_process_group(backend=os.environ.get('OAKE_BENCH_BACKEND', 'nccl'))
 
     from oadp_amd import _lib, clip
     from oadp_amd.weights import synthetic_state_dict
