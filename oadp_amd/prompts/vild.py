@@ -15,12 +15,27 @@ from typing import Callable, Iterable, Sequence
 
 import torch
 
-TEMPLATES_FILE = pathlib.Path(__file__).with_name('vild_templates.txt')
 SOT, EOT, CONTEXT = 49406, 49407, 77  # clip/simple_tokenizer.py: <|startoftext|>, <|endoftext|>
 
 
 def templates() -> list[str]:
-    return [ln for ln in TEMPLATES_FILE.read_text().splitlines() if ln and not ln.startswith('#')]
+    """The 74 ViLD templates in the reference's order (oadp/prompts/vild.py:9-51): they are the product
+    of a few word choices — {This is, There is} x {a, the, one} x {-, small, medium, large} x
+    {-, in the scene / photo / picture} plus the "a photo of" family — generated here."""
+    sizes = ['', 'small ', 'medium ', 'large ']
+    arts = ['a', 'the', 'one']
+    out = ['This is a {}', 'There is a {}']
+    out += [f'a photo of a {s}{{}} in the scene' for s in sizes]
+    out += [f'a photo of a {s}{{}}' for s in sizes]
+    out += [f'This is a photo of a {s}{{}}' for s in sizes]
+    out += [f'There is {a} {{}} in the scene' for a in arts]
+    out += [f'This is {a} {{}} in the scene' for a in arts]
+    out += [f'This is one {s}{{}} in the scene' for s in sizes[1:]]
+    out += [f'There is a {s}{{}} in the scene' for s in sizes[1:]]
+    for head, place in (('There is', 'photo'), ('There is', 'picture'), ('This is', 'photo'),
+                        ('This is', 'picture')):
+        out += [f'{head} {a} {s}{{}} in the {place}' for s in sizes for a in arts]
+    return out
 
 
 def adaptively_tokenize(texts: Iterable[str], encode: Callable[[str], Sequence[int]], *,

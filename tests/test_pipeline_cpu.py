@@ -224,8 +224,12 @@ def test_vild_prompt_tokenisation():
     """oadp_amd/prompts/vild.py: 74 templates; adaptively_tokenize = SOT ids EOT, zero padded, context
     trimmed to the longest row, EOT the highest id of every row (what encode_text's argmax relies on)."""
     from oadp_amd.prompts import vild
+    import hashlib
     t = vild.templates()
     assert len(t) == 74 and all('{}' in s for s in t) and t[0] == 'This is a {}'
+    # digest of the reference's own `prompts` list (oadp/prompts/vild.py:9-51), taken in this container
+    assert hashlib.sha256('\n'.join(t).encode()).hexdigest() == \
+        '327954310ab55c5c8cbd29b60139100178fd3d7564fe8924496b001d99091b1a'
     enc = lambda s: [1 + (hash(w) % 1000) for w in s.split()]
     tok = vild.adaptively_tokenize(['a photo of a cat', 'dog'], enc)
     assert tok.dtype == torch.int32 and tok.shape == (2, 7)
