@@ -1,5 +1,5 @@
+# Blocks mode: multi-scale 224x224 tiles per image (reference configs/oake/blocks.py).
 _base_ = ['base.py']
-_OUT = 'data/coco/oake/blocks'
-train = dict(dataloader=dict(dataset=dict(output_dir=f'{_OUT}/train2017')))
-val = dict(dataloader=dict(dataset=dict(output_dir=f'{_OUT}/val2017')))
+train, val = (dict(dataloader=dict(dataset=dict(output_dir=f'data/coco/oake/blocks/{s}2017')))
+              for s in ('train', 'val'))
 log = dict(interval=10)

@@ -1,5 +1,5 @@
+# Globals mode: one CLIP-preprocessed crop per image (reference configs/oake/globals.py).
 _base_ = ['base.py']
-_OUT = 'data/coco/oake/globals'
-train = dict(dataloader=dict(dataset=dict(output_dir=f'{_OUT}/train2017')))
-val = dict(dataloader=dict(dataset=dict(output_dir=f'{_OUT}/val2017')))
+train, val = (dict(dataloader=dict(dataset=dict(output_dir=f'data/coco/oake/globals/{s}2017')))
+              for s in ('train', 'val'))
 log = dict(interval=50)

@@ -1,9 +1,13 @@
+# Objects mode on LVIS v1 (COCO images, LVIS annotations; reference configs/oake/objects_lvis.py).
 _base_ = ['objects_coco.py']
-_OUT = 'data/lvis_v1/oake/objects'
-_PROP = 'data/lvis_v1/proposals'
-train = dict(dataloader=dict(dataset=dict(
-    type='LVISDataset', root='data/coco', annFile='data/lvis_v1/annotations/lvis_v1_train.json',
-    output_dir=f'{_OUT}/train2017', proposal_file=f'{_PROP}/oln_r50_fpn_lvis_train.pkl')))
-val = dict(dataloader=dict(dataset=dict(
-    type='LVISDataset', root='data/coco', annFile='data/lvis_v1/annotations/lvis_v1_val.json',
-    output_dir=f'{_OUT}/val2017', proposal_file=f'{_PROP}/oln_r50_fpn_lvis_val.pkl')))
+
+
+def _split(name):
+    return dict(dataloader=dict(dataset=dict(
+        type='LVISDataset', root='data/coco',
+        annFile=f'data/lvis_v1/annotations/lvis_v1_{name}.json',
+        output_dir=f'data/lvis_v1/oake/objects/{name}2017',
+        proposal_file=f'data/lvis_v1/proposals/oln_r50_fpn_lvis_{name}.pkl')))
+
+
+train, val = _split('train'), _split('val')
