@@ -1,5 +1,5 @@
 """Per-tile cycle anatomy of the production GEMM (gemm_pp_kernel) — GPU box only.
-usage: gemm_trace.py M N K [gelu|bias|f32]"""
+usage: gemm_trace.py M N K [gelu|bias|f32|resid]"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,8 +13,13 @@ a = (torch.randn(m, k, device=dev) * 0.5).half(); w = (torch.randn(n, k, device=
 bias = torch.randn(n, device=dev)
 c = torch.empty(m, n, device=dev, dtype=torch.float32 if mode == 'f32' else torch.float16)
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+xres = torch.randn(m + 1, n, device=dev).half()
+part = torch.zeros((m + 1) * 32, device=dev)
 def run():
-    if mode == 'f32':
+    if mode == 'resid':
+        lib.oake_debug_gemm_resid16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), xres.data_ptr(), part.data_ptr(),
+                                    m, n, k, 1, s)
+    elif mode == 'f32':
         lib.oake_debug_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, 1, s)
     else:
         lib.oake_debug_gemm16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, 1, int(mode == 'gelu'), s)
