@@ -1,0 +1,234 @@
+"""Reading the OAKE features back during detector training.
+
+The reference's detector pipeline does three ``torch.load`` calls per training sample — one small
+pickle each for globals / blocks / objects — through ``todd.datasets.PthAccessLayer``
+(oadp/dp/datasets.py:137-214, configs/dp/datasets/ov_coco.py:23-32).  Two access layers with the
+same ``Mapping[str, ...]`` face live here:
+
+* ``PthAccessLayer``: the per-image ``{data_root}/{task_name}/{key}.pth`` files exactly as
+  ``oadp_amd.oake`` (and the reference) write them;
+* ``PackAccessLayer``: one memory-mapped blob per (mode, split) made by ``pack()`` from those files.
+  A lookup is an index probe + zero-copy views of the map: no unpickling, no per-sample file open,
+  and the page cache is shared by all dataloader workers.  Values are bit-identical to the
+  ``.pth`` path (tests/test_dp_features.py).
+
+``LoadCLIPFeatures`` is the pipeline step (same result keys, same filtering) on plain tensors /
+arrays; the mmdet registry and ``todd.BBoxesXYXY`` are replaced by the few lines of box arithmetic
+they stand for ([RECALL] ``a & b`` = pairwise intersection areas, ``indices(min_wh)`` as in
+oadp_amd/oake/objects.py).
+"""
+from __future__ import annotations
+
+import json
+import os
+import pathlib
+from collections.abc import Iterator, Mapping
+from typing import Any
+
+import numpy as np
+import torch
+
+from ..oake.objects import indices_min_wh
+from ..store import Store
+
+_MAGIC = 'oake-pack-1'
+_ALIGN = 64
+_DTYPES = {torch.float16: 'float16', torch.float32: 'float32', torch.float64: 'float64',
+           torch.int64: 'int64', torch.int32: 'int32', torch.uint8: 'uint8', torch.bool: 'bool'}
+
+
+class PthAccessLayer(Mapping):
+    """``{data_root}/{task_name}/{key}.pth`` -> ``torch.load(..., 'cpu')``."""
+
+    def __init__(self, data_root: str, task_name: str = '', **_: Any) -> None:
+        self._dir = pathlib.Path(data_root) / task_name
+
+    def __getitem__(self, key: str) -> Any:
+        path = self._dir / f'{key}.pth'
+        if not path.exists():
+            raise KeyError(key)
+        return torch.load(path, map_location='cpu')
+
+    def __iter__(self) -> Iterator[str]:
+        return (p.stem for p in sorted(self._dir.glob('*.pth')))
+
+    def __len__(self) -> int:
+        return sum(1 for _ in self._dir.glob('*.pth'))
+
+
+def _fields(value: Any) -> list[tuple[str, torch.Tensor]]:
+    """A feature file holds a tensor (globals) or a flat dict of tensors (blocks, objects)."""
+    if isinstance(value, torch.Tensor):
+        return [('', value)]
+    if isinstance(value, dict) and all(isinstance(v, torch.Tensor) for v in value.values()):
+        if '' in value:
+            raise ValueError('empty field name')
+        return list(value.items())
+    raise TypeError(f'cannot pack {type(value).__name__}: expected a tensor or a dict of tensors')
+
+
+def pack(data_root: str, task_name: str, out: str | None = None) -> pathlib.Path:
+    """Gather ``{data_root}/{task_name}/*.pth`` into ``{data_root}/{task_name}.pack`` (+ ``.json``
+    index: key -> [[field, dtype, shape, byte offset], ...]; tensors 64-byte aligned, C order).
+    The index is written last, by rename, so a reader never sees a half-written pack."""
+    src = PthAccessLayer(data_root, task_name)
+    blob = pathlib.Path(out) if out is not None else pathlib.Path(data_root) / f'{task_name}.pack'
+    index: dict[str, list] = {}
+    offset = 0
+    tmp = blob.with_name(blob.name + f'.tmp{os.getpid()}')
+    with open(tmp, 'wb') as f:
+        for key in src:
+            entry = []
+            for name, t in _fields(src[key]):
+                if t.dtype not in _DTYPES:
+                    raise TypeError(f'{key}: dtype {t.dtype} is not packable')
+                pad = -offset % _ALIGN
+                f.write(b'\0' * pad)
+                offset += pad
+                data = t.detach().contiguous().numpy().tobytes()
+                f.write(data)
+                entry.append([name, _DTYPES[t.dtype], list(t.shape), offset])
+                offset += len(data)
+            index[key] = entry
+    os.replace(tmp, blob)
+    meta = blob.with_name(blob.name + '.json')
+    tmp = meta.with_name(meta.name + f'.tmp{os.getpid()}')
+    tmp.write_text(json.dumps(dict(magic=_MAGIC, bytes=offset, index=index)))
+    os.replace(tmp, meta)
+    return blob
+
+
+class PackAccessLayer(Mapping):
+    """Read side of ``pack()``.  Tensors are read-only views of one shared memory map (opened lazily,
+    so the object pickles cheaply into dataloader workers); ``copy=True`` hands out private copies
+    for callers that write into what they load."""
+
+    def __init__(self, data_root: str, task_name: str = '', copy: bool = False, **_: Any) -> None:
+        self._blob = pathlib.Path(data_root) / f'{task_name}.pack'
+        meta = json.loads(self._blob.with_name(self._blob.name + '.json').read_text())
+        if meta.get('magic') != _MAGIC:
+            raise ValueError(f'{self._blob}: not an OAKE feature pack')
+        if self._blob.stat().st_size != meta['bytes']:
+            raise ValueError(f'{self._blob}: size does not match its index (truncated pack?)')
+        self._index: dict[str, list] = meta['index']
+        self._copy = copy
+        self._map: np.memmap | None = None
+
+    def __getstate__(self) -> dict:
+        return dict(self.__dict__, _map=None)
+
+    def _view(self, dtype: str, shape: list[int], offset: int) -> torch.Tensor:
+        if self._map is None:
+            self._map = np.memmap(self._blob, dtype=np.uint8, mode='r') if self._blob.stat().st_size \
+                else np.zeros(0, np.uint8)
+        n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        a = self._map[offset:offset + n].view(dtype).reshape(shape)
+        if self._copy:
+            return torch.from_numpy(np.array(a))
+        import warnings
+        with warnings.catch_warnings():  # read-only map: torch warns that writes are undefined
+            warnings.simplefilter('ignore', UserWarning)
+            return torch.from_numpy(a)
+
+    def __getitem__(self, key: str) -> Any:
+        entry = self._index[key]
+        if len(entry) == 1 and entry[0][0] == '':
+            return self._view(*entry[0][1:])
+        return {name: self._view(dtype, shape, offset) for name, dtype, shape, offset in entry}
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self._index)
+
+    def __len__(self) -> int:
+        return len(self._index)
+
+
+ACCESS_LAYERS = dict(PthAccessLayer=PthAccessLayer, PackAccessLayer=PackAccessLayer)
+
+
+def build_access_layer(config: Mapping[str, Any], default: Mapping[str, Any]) -> Mapping[str, Any]:
+    """``ALR.build(config, default)``: ``default`` supplies the keys ``config`` leaves out."""
+    cfg = {**default, **config}
+    return ACCESS_LAYERS[cfg.pop('type')](**cfg)
+
+
+def pairwise_intersection(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[na, nb] intersection areas of xyxy boxes."""
+    lt = torch.maximum(a[:, None, :2], b[None, :, :2])
+    rb = torch.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp_min(0)
+    return wh[..., 0] * wh[..., 1]
+
+
+class LoadCLIPFeatures:
+    """Pipeline step of oadp/dp/datasets.py:137-214.  ``results`` in/out keys as the reference:
+    reads ``img_info.id``, ``bbox_fields``, optionally ``gt_bboxes`` / ``gt_labels``; writes
+    ``clip_global``, ``clip_blocks`` / ``block_bboxes`` / ``block_labels``, ``clip_objects`` /
+    ``object_bboxes``.  ``num_all`` is ``Globals.categories.num_all`` there (labels >= num_all are
+    pseudo labels and do not mark blocks)."""
+
+    def __init__(self, default: Mapping[str, Any], globals_: Mapping[str, Any] | None = None,
+                 blocks: Mapping[str, Any] | None = None, objects: Mapping[str, Any] | None = None,
+                 num_all: int = 65) -> None:
+        if globals_ is None and blocks is None and objects is None:
+            raise ValueError('at least one of globals_, blocks, objects is required')
+        default = dict(default)
+        if os.environ.get('TRAIN_WITH_VAL_DATASET', '').lower() in ('1', 'true', 'yes', 'on'):
+            default['task_name'] = default['task_name'].replace('train', 'val')
+        self._num_all = num_all
+        self._globals, self._blocks, self._objects = (
+            None if c is None else build_access_layer(c, default) for c in (globals_, blocks, objects))
+        self._dry_key: str | None = None
+        if Store.DRY_RUN:
+            layers = [m for m in (self._globals, self._blocks, self._objects) if m is not None]
+            self._dry_key = sorted(set.intersection(*(set(m.keys()) for m in layers)))[0]
+
+    def __call__(self, results: dict[str, Any]) -> dict[str, Any]:
+        key = self._dry_key if self._dry_key is not None else f'{results["img_info"]["id"]:012d}'
+        bbox_fields: list[str] = results['bbox_fields']
+
+        if self._globals is not None:
+            results['clip_global'] = self._globals[key].squeeze(0)
+
+        if self._blocks is not None:
+            blocks = self._blocks[key]
+            block_bboxes = blocks['bboxes']
+            if 'gt_bboxes' in results:
+                gt_bboxes = np.asarray(results['gt_bboxes'])
+                gt_labels = np.asarray(results['gt_labels'])
+                real = gt_labels < self._num_all
+                gt_bboxes, gt_labels = gt_bboxes[real], gt_labels[real]
+                # f16 block boxes against f32 ground truth: torch promotes to f32, as here
+                overlap = pairwise_intersection(
+                    block_bboxes.float(), torch.as_tensor(gt_bboxes, dtype=torch.float32).reshape(-1, 4)) > 0
+                block_ids, gt_ids = torch.where(overlap)
+                block_labels = np.zeros((block_bboxes.shape[0], self._num_all), dtype=bool)
+                block_labels[block_ids.numpy(), gt_labels[gt_ids.numpy()]] = True
+                results['block_labels'] = block_labels
+            results['clip_blocks'] = blocks['embeddings']
+            results['block_bboxes'] = block_bboxes.float().numpy()
+            bbox_fields.append('block_bboxes')
+
+        if self._objects is not None:
+            objects = self._objects[key]
+            object_bboxes = objects['bboxes']
+            keep = indices_min_wh(object_bboxes, (4, 4))
+            results['clip_objects'] = objects['embeddings'][keep]
+            results['object_bboxes'] = object_bboxes[keep].float().numpy()
+            bbox_fields.append('object_bboxes')
+
+        return results
+
+
+def main() -> None:
+    import argparse
+    p = argparse.ArgumentParser(description='pack per-image OAKE feature files into one mappable blob')
+    p.add_argument('data_root')
+    p.add_argument('task_name')
+    a = p.parse_args()
+    blob = pack(a.data_root, a.task_name)
+    print(f'{blob}: {blob.stat().st_size} bytes, {len(PackAccessLayer(a.data_root, a.task_name))} keys')
+
+
+if __name__ == '__main__':
+    main()
