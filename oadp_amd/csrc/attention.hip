@@ -142,8 +142,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
           sacc[kt][mt][r] = s;
           mx = fmaxf(mx, s);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows16_max(mx);
       const float m_new = fmaxf(m_run[mt], mx);
       const float alpha = __expf(m_run[mt] - m_new);
       float sum = 0.f;
@@ -155,8 +154,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
           sacc[kt][mt][r] = p;
           sum += p;
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows16_sum(sum);
       l_run[mt] = l_run[mt] * alpha + sum;
       m_run[mt] = m_new;
 #pragma unroll
@@ -373,8 +371,7 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
 #pragma unroll
       for (int j = 0; j < 8; ++j) s_self += to32<T>(qf[0][kk][j]) * to32<T>(kv[j]);
     }
-    s_self += __shfl_xor(s_self, 16, 64);
-    s_self += __shfl_xor(s_self, 32, 64);
+    s_self = rows16_sum(s_self);
   }
   float m_run[MT], l_run[MT];
   f32x4 oacc[4][MT];
@@ -460,8 +457,7 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
               mx = fmaxf(mx, sv);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows16_max(mx);
         const float m_new = fmaxf(m_run[mt], mx);
         const float alpha = __expf(m_run[mt] - m_new);
         float sum = 0.f;
@@ -473,8 +469,7 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
             sacc[kt][mt][r] = p;
             sum += p;
           }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows16_sum(sum);
         l_run[mt] = l_run[mt] * alpha + sum;
         m_run[mt] = m_new;
 #pragma unroll

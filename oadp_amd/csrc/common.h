@@ -74,6 +74,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Reductions over lanes l, l^16, l^32, l^48 — the four 16-lane rows of a wave, i.e. the four lanes
+// that hold one row (column) of a 16x16 MFMA accumulator tile — with the gfx950 row swaps:
+// v_permlane16_swap / v_permlane32_swap are plain VALU instructions, where __shfl_xor compiles to
+// ds_bpermute_b32, a round trip through the LDS crossbar with an lgkmcnt wait per butterfly level.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rows16_sum(float v) {
+  u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float rows16_max(float v) {
+  u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // QuickGELU (OpenAI CLIP): x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)).
 // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division: the result is rounded to 16 bits
 // right after, and the c_fc epilogue evaluates this 80 times per lane per tile.

@@ -159,6 +159,26 @@ struct EpiLds {
   static constexpr int kBytes = 2048 + 160 * 8;
 };
 
+// Row-octet exchange of 16-byte pieces between lanes r and r ^ 8 of each 16-lane row.  For the
+// lanes selected by `low` (true: rows 8-15, false: rows 0-7) the result is the partner's `theirs`;
+// the other lanes keep `mine`.  One bank-masked row_ror:8 DPP move per register.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <typename V>
+__device__ __forceinline__ V swap_piece(V mine, V theirs, bool take_in_upper_rows) {
+  static_assert(sizeof(V) == 16, "16-byte pieces");
+  u32x4_t m, t, o;
+  __builtin_memcpy(&m, &mine, 16);
+  __builtin_memcpy(&t, &theirs, 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = take_in_upper_rows
+               ? (unsigned)__builtin_amdgcn_update_dpp((int)m[i], (int)t[i], 0x128, 0xF, 0xC, false)
+               : (unsigned)__builtin_amdgcn_update_dpp((int)m[i], (int)t[i], 0x128, 0xF, 0x3, false);
+  V out;
+  __builtin_memcpy(&out, &o, 16);
+  return out;
+}
+
 template <bool ELDS>
 __device__ __forceinline__ float4 epi_vec4(const float* gptr, int n, const char* elds, int off, int lc) {
   if constexpr (ELDS)
@@ -192,6 +212,37 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
         c1[t] = okc ? epi_vec4<ELDS>(ep.colsum, n + 4, elds, EpiLds::kColsum, lc + 4) : z4;
       }
     }
+    // Residual stream: a row block's 16-B pieces are fetched kAhead row blocks before they are used.
+    // x is read and written through the same pointer, so hipcc keeps every load behind the stores
+    // that precede it in program order: fetched row by row at the point of use, that was MI
+    // dependent round trips to L2 per tile (10k cycles of epilogue); all MI rows up front would not fit
+    // the persistent kernel's 168 registers next to the accumulators.
+    constexpr int kAhead = 2;
+    // Full-line accesses (interior tiles; tools/ubench/store_bench.hip): a lane's two 16-B pieces of
+    // row r are the two halves of ONE 128-B line, so a store instruction in accumulator layout
+    // writes 16 half lines — measured 5.6k cycles for the CU's 80 KiB tile-end burst against 3.8k
+    // (all CUs; 1.6k with few) for instructions of 8 full lines.  Lanes r and r ^ 8 therefore swap
+    // one piece each (one row_ror:8 DPP move per register, bank-masked so no selects): piece A goes
+    // to / comes from row (r & 7), piece B row 8 + (r & 7), both at column 32 (r >> 3) + 8 g.
+    constexpr bool SWAP = FULL && NP == 2 && EPI != EPI_PATCH16;
+    const int frow_ = threadIdx.x & 15;
+    const int swap_row = SWAP ? (frow_ & 7) - frow_ : 0;       // row of piece A relative to the lane's own
+    const int swap_col = SWAP ? ((frow_ & 8) ? 32 : 0) : 0;    // column of both pieces relative to 8 g
+    vec8 xres[EPI == EPI_RESID16 ? MI : 1][NP];
+#define OAKE_FETCH_RESID(mi_)                                                                   \
+  do {                                                                                          \
+    _Pragma("unroll") for (int _t = 0; _t < NP; ++_t) {                                         \
+      const int _m = mbase + (mi_) * 16 + (SWAP ? swap_row + 8 * _t : 0);                       \
+      const int _n = nwave + 8 * g + (SWAP ? swap_col : 32 * _t);                               \
+      if (FULL || (_m < M && _n < N))                                                           \
+        xres[mi_][_t] = *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(ep.out) +     \
+                                                       (size_t)_m * ep.ldo + _n);               \
+    }                                                                                           \
+  } while (0)
+    if constexpr (EPI == EPI_RESID16) {
+#pragma unroll
+      for (int mi = 0; mi < (kAhead < MI ? kAhead : MI); ++mi) OAKE_FETCH_RESID(mi);
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = mbase + mi * 16;
@@ -215,13 +266,16 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
       float ps1 = 0.f, ps2 = 0.f;  // this lane's share of the row's (sum x, sum x^2)
       // this row's residual (8 x 16-bit) / pos-emb (8 x fp32) loads first, then the stores
       vec8 xr[NP];
+      u32x4_t qv[SWAP ? NP : 1];
       float4 p0[NP], p1[NP];
 #pragma unroll
       for (int t = 0; t < NP; ++t) {
         const int n = nwave + 32 * t + 8 * g;
         const bool ok = FULL || (mok && n < N);
         if (EPI == EPI_RESID16) {
-          if (ok) xr[t] = *reinterpret_cast<const vec8*>(orow_ptr + n);
+          // own piece t: fetched by this lane (A for rows < 8, B for rows >= 8) or by lane r ^ 8
+          const vec8 own = xres[EPI == EPI_RESID16 ? mi : 0][t];
+          xr[t] = SWAP ? swap_piece(own, xres[EPI == EPI_RESID16 ? mi : 0][NP - 1 - t], t == 0) : own;
         } else if (EPI == EPI_PATCH16) {
           p0[t] = ok ? *reinterpret_cast<const float4*>(posrow + n) : make_float4(0.f, 0.f, 0.f, 0.f);
           p1[t] = ok ? *reinterpret_cast<const float4*>(posrow + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,19 +322,29 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
         }
         const uint2 q0 = pack4<T>(lo[0], lo[1], lo[2], lo[3]);
         const uint2 q1 = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
-        *reinterpret_cast<uint4*>(orow_ptr + n) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+        if constexpr (SWAP)
+          qv[t] = u32x4_t{q0.x, q0.y, q1.x, q1.y};
+        else
+          *reinterpret_cast<uint4*>(orow_ptr + n) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+      }
+      if constexpr (SWAP) {
+        T* pa = orow_ptr + (ptrdiff_t)swap_row * ep.ldo + nwave + 8 * g + swap_col;
+        *reinterpret_cast<u32x4_t*>(pa) = swap_piece(qv[0], qv[1], true);
+        *reinterpret_cast<u32x4_t*>(pa + (size_t)8 * ep.ldo) = swap_piece(qv[1], qv[0], false);
+      }
+      if constexpr (EPI == EPI_RESID16) {
+        if (mi + kAhead < MI) OAKE_FETCH_RESID(mi + kAhead < MI ? mi + kAhead : 0);
       }
       if constexpr (ELDS && EPI == EPI_RESID16) {
         if (ep.rowpart_out != nullptr) {  // (uniform) the wave's 64-column slice of row m
           static_assert(NI * 16 == 64, "row-statistics slices are 64 columns wide");
-          ps1 += __shfl_xor(ps1, 16, 64);
-          ps2 += __shfl_xor(ps2, 16, 64);
-          ps1 += __shfl_xor(ps1, 32, 64);
-          ps2 += __shfl_xor(ps2, 32, 64);
+          ps1 = rows16_sum(ps1);
+          ps2 = rows16_sum(ps2);
           if (g == 0 && mok) ep.rowpart_out[(size_t)m * kRowParts + nwave / 64] = make_float2(ps1, ps2);
         }
       }
     }
+#undef OAKE_FETCH_RESID
     return;
   }
   // fp32 outputs: lane owns columns nwave + 16 ni + 4 g .. +3 of each column tile
@@ -585,7 +649,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     // producer cursor: flat K-tile s_g (k position s_kt of tile s_tile) goes to ring slot s_buf
     int s_g = 0, s_kt = 0, s_tile = 0, s_buf = 0;
     // consumer position (compute group 0): K-tile d_kt of tile d_tile.  In the last phase of a tile's
-    // FIRST K-tile (group 1 finished the previous tile's epilogue one phase earlier) one DMA wave
+    // FIRST K-tile (group 1 finished the previous tile's epilogue two phases earlier) one DMA wave
     // each stages the tile's bias / colsum block into the EpiLds area; it is covered by
     // the next iteration's vmcnt wait + barrier, long before the tile's epilogue (nk >= 3).
     int d_kt = 0, d_tile = 0;
@@ -643,7 +707,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     OAKE_BAR();  // b0: flat K-tile 0 published
     // LN-folded epilogues: DMA wave lw owns rows [lw * BM/4, +BM/4) of the tile, one row per lane.  At
     // the tile's first K-tile it loads the row's partial (sum x, sum x^2) slices, adds them up in
-    // slot order and — one barrier later, when group 1 is done with the previous tile's epilogue —
+    // slot order and — two barriers later, when group 1 is done with the previous tile's epilogue (it
+    // runs in the second phase of the new tile's first K-tile, group 0's in the first) —
     // writes (rstd, -mean rstd) into EpiLds::kRowstat, 11 K-tiles ahead of the epilogue that reads it.
     // (hipcc guards the loaded values with s_waitcnt vmcnt(0): once per tile this wave also waits
     // for its newest pieces.)
@@ -682,6 +747,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       }
       OAKE_STAGE(0, Q1);  // flat K-tile g+2, a quarter of the pieces per phase
       OAKE_BAR();
+      OAKE_STAGE(Q1, Q2);
+      OAKE_BAR();
       if constexpr (LN) {
         if (d_kt == 0 && lane < RPW) {
           typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -690,8 +757,6 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
               f32x2{st_rstd, st_shift};
         }
       }
-      OAKE_STAGE(Q1, Q2);
-      OAKE_BAR();
       OAKE_STAGE(Q2, Q3);
       OAKE_BAR();
       OAKE_STAGE(Q3, NPL);
@@ -791,6 +856,10 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     OAKE_BAR();
     OAKE_MFMA_BLOCK();
     c_buf = c_buf == NSTAGE - 1 ? 0 : c_buf + 1;
+    // The epilogue runs AFTER the barrier that ends the tile's last MFMA phase, i.e. in the first phase
+    // of the next tile's first K-tile: group 0's overlaps group 1's last MFMA phase, group 1's (one
+    // phase later) group 0's first, instead of holding the partner wave at the barrier throughout.
+    OAKE_BAR();
     if (++c_kt == nk) {
       // tile done
       c_kt = 0;
@@ -837,7 +906,6 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
         }
       }
     }
-    OAKE_BAR();
   }
   if (!late) OAKE_BAR();
   if constexpr (TRICKLE) {
