@@ -275,7 +275,8 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
 /* Attention variant bits: 1 = ds_read_b64_tr_b16 V fragments (else 16-bit LDS gathers),
  * 2 = 32 queries per wave (else 64), 4 = sequences longer than 64 keys share K / V through LDS between
  * the four waves of a block, 8 = objects mode: the object token's attention rides on an idle wave
- * of that kernel.  Default 15. */
+ * of that kernel, 16 = sequences of at most 64 keys without a causal mask: the two waves of a (crop,
+ * head) share its K / V in LDS, staged with LDS-DMA.  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
 /* GEMM configuration: -1 = automatic per shape, 0..4 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);

@@ -29,6 +29,7 @@ extern int g_attention_use_tr;
 extern int g_attention_q32;
 extern int g_attention_coop;
 extern int g_attention_fuse_obj;
+extern int g_attention_pair;
 extern int g_gemm_variant;
 extern int g_gemm_panel;
 extern unsigned long long* g_gemm_trace;
@@ -1348,6 +1349,7 @@ int oake_debug_set_attention_variant(int variant) {
   oake::g_attention_q32 = (variant & 2) ? 1 : 0;
   oake::g_attention_coop = (variant & 4) ? 1 : 0;
   oake::g_attention_fuse_obj = (variant & 8) ? 1 : 0;
+  oake::g_attention_pair = (variant & 16) ? 1 : 0;
   return OAKE_OK;
 }
 

@@ -28,7 +28,7 @@ constexpr int kVStride = 72;                       // halves per V row in LDS (6
 constexpr int kVBytesPerWave = 64 * kVStride * 2;  // 9216
 
 template <typename T, bool USE_TR, int MT>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3 : 1, MT == 2 ? 3 : 2))) void attention_kernel(const T* __restrict__ qkv,
                                                         T* __restrict__ out, int L, int H, int QB,
                                                         int total_waves, int causal) {
   typedef typename T16<T>::vec8 vec8;
@@ -49,15 +49,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   const int q0 = qb * (16 * MT);
   T* vs = reinterpret_cast<T*>(smem + wid * kVBytesPerWave);
 
-  // Q fragments (B operand): Q[q0 + 16 mt + fr][32 kk + 8 g .. +8)
+  // Q fragments (B operand): Q[q0 + 16 mt + fr][32 kk + 8 g .. +8), fetched as full 128-B lines and
+  // un-swapped between lanes fr and fr ^ 8 (common.h, swap_piece)
+  const int sw_row = fr & 7, sw_col = (fr & 8) * 4 + g * 8;  // piece A: row sw_row, B: row 8 + sw_row
   vec8 qf[MT][2];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    int r = q0 + mt * 16 + fr;
-    r = r < L ? r : L - 1;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      qf[mt][kk] = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + kk * 32 + g * 8);
+    int ra = q0 + mt * 16 + sw_row, rb = ra + 8;
+    ra = ra < L ? ra : L - 1;
+    rb = rb < L ? rb : L - 1;
+    const vec8 pa = *reinterpret_cast<const vec8*>(base + (size_t)ra * ld + sw_col);
+    const vec8 pb = *reinterpret_cast<const vec8*>(base + (size_t)rb * ld + sw_col);
+    qf[mt][0] = swap_piece(pa, pb, true);
+    qf[mt][1] = swap_piece(pb, pa, false);
   }
 
   float m_run[MT], l_run[MT];
@@ -86,15 +90,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         vreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)r * ld + 2 * C + vc * 8);
       }
     }
-    vec8 kfr[MT == 2 ? 4 : 1][2];
+    vec8 kfr[MT == 2 ? 4 : 1][2];  // (raw pieces A, B here; un-swapped at the point of use)
     if (MT == 2) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        int r = k0 + kt * 16 + fr;
-        r = r < L ? r : L - 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          kfr[kt][kk] = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + C + kk * 32 + g * 8);
+        int ra = k0 + kt * 16 + sw_row, rb = ra + 8;
+        ra = ra < L ? ra : L - 1;
+        rb = rb < L ? rb : L - 1;
+        kfr[kt][0] = *reinterpret_cast<const vec8*>(base + (size_t)ra * ld + C + sw_col);
+        kfr[kt][1] = *reinterpret_cast<const vec8*>(base + (size_t)rb * ld + C + sw_col);
       }
     }
     {  // V -> LDS: lane -> (row = lane/8 + 8 i, 16-B chunk = lane%8)
@@ -112,15 +116,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
       for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      int r = k0 + kt * 16 + fr;
-      r = r < L ? r : L - 1;
+      vec8 pa, pb;
+      if (MT == 2) {
+        pa = kfr[kt][0];
+        pb = kfr[kt][1];
+      } else {
+        int ra = k0 + kt * 16 + sw_row, rb = ra + 8;
+        ra = ra < L ? ra : L - 1;
+        rb = rb < L ? rb : L - 1;
+        pa = *reinterpret_cast<const vec8*>(base + (size_t)ra * ld + C + sw_col);
+        pb = *reinterpret_cast<const vec8*>(base + (size_t)rb * ld + C + sw_col);
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        vec8 kf;
-        if (MT == 2)
-          kf = kfr[kt][kk];
-        else
-          kf = *reinterpret_cast<const vec8*>(base + (size_t)r * ld + C + kk * 32 + g * 8);
+        const vec8 kf = kk == 0 ? swap_piece(pa, pb, true) : swap_piece(pb, pa, false);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
       }
@@ -209,19 +218,205 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     __builtin_amdgcn_wave_barrier();
   }
 
-  // ---- normalise and store: lane holds O[query = 16 mt + fr][d = 16 dt + 4 g + 0..3] ----
+  // ---- normalise and store: lane holds O[query = 16 mt + fr][d = 16 dt + 4 g + 0..3], i.e. 8-B pieces
+  //      of 16 different rows: stored like that, an instruction touches 16 quarter lines (measured:
+  //      7.7 B/cycle/CU, a third of this kernel's time).  The tile goes through the wave's V staging
+  //      area instead (free after the last PV) and leaves as 8 rows x 128 B per instruction. ----
   T* obase = out + (size_t)img * L * C + h * kHeadDim;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int q = q0 + mt * 16 + fr;
-    if (q >= L) continue;
     const float inv = 1.0f / l_run[mt];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const f32x4 o = oacc[dt][mt];
-      *reinterpret_cast<uint2*>(obase + (size_t)q * C + dt * 16 + 4 * g) =
+      *reinterpret_cast<uint2*>(vs + (mt * 16 + fr) * kVStride + dt * 16 + 4 * g) =
           pack4<T>(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
     }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 2 * MT; ++i) {
+    const int row = (lane >> 3) + 8 * i;
+    const uint4 v = *reinterpret_cast<const uint4*>(vs + row * kVStride + (lane & 7) * 8);
+    if (q0 + row < L)
+      *reinterpret_cast<uint4*>(obase + (size_t)(q0 + row) * C + (lane & 7) * 8) = v;
+  }
+}
+
+// ---- attention for short sequences (L <= 64, no causal mask: encode_image and blocks mode) ----
+// attention_kernel above is latency-bound at L = 50: a wave stages its own K and V through 64 of its
+// 160-175 registers, K and V are fetched once per 32-query wave, and two or three such waves fit a SIMD.
+// Here the two waves that share a (crop, head) item share its K and V in LDS:
+//   * a block is 4 waves = 2 items.  Of an item's pair of waves one moves the K rows, the other the V
+//     rows, with LDS-DMA (global_load_lds_dwordx4: 8 rows x 128 B per instruction, no registers); each
+//     fetches its own 32 Q rows straight into fragment registers (full lines + swap_piece).  One block
+//     barrier.
+//   * LDS rows are 128 B with the 16-B chunks XOR-swizzled by (row >> 1) & 7 on the source side (as in
+//     gemm.hip), so the K fragment reads (ds_read_b128) and the V transpose reads
+//     (ds_read_b64_tr_b16) are conflict-free without padding.
+//   * a region holds exactly L rows: [V0 V1 K0 K1 pad].  The MFMA tiles read 64 rows; rows past L of a
+//     V region are the first rows of the next region — finite 16-bit data, multiplied by P = 0
+//     exactly —, rows past L of a K region only produce scores that the key mask discards.  At L = 50
+//     that is 27 KB per block and 72 registers: five blocks = 20 waves per CU.  (Measured at batch 256:
+//     2 items per block 14.4 us; 3 items, i.e. the whole batch resident at once, 17.6 — every block
+//     then loads, computes and stores in step and nothing overlaps; 1 item 17.3; attention_kernel 18.0.)
+//   * O leaves through the wave's half of the K rows (after a second barrier): 8 rows x 128 B per store.
+constexpr int kPairItems = 2;
+constexpr float kLog2e = 1.4426950408889634f;
+
+__host__ __device__ constexpr int pair_lds_bytes(int L) { return (2 * kPairItems * L + (64 - L)) * 128; }
+
+template <typename T>
+__global__ __launch_bounds__(2 * kPairItems * 64) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void attention_pair_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int H, int items) {
+  typedef typename T16<T>::vec8 vec8;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wid >> 1, qb = wid & 1, q0 = qb * 32;
+  const int item_raw = blockIdx.x * kPairItems + pair;
+  const bool valid = item_raw < items;  // (a ragged item count leaves the last pairs idle: they replay
+  const int item = valid ? item_raw : items - 1;  // the last item so that every wave takes both barriers)
+  const int img = item / H, h = item - img * H;
+  const int C = H * kHeadDim;
+  const size_t ld = (size_t)3 * C;
+  const T* base = qkv + (size_t)img * L * ld + h * kHeadDim;
+  const int region = L * 128;
+  char* vs = smem + pair * region;
+  char* ks = smem + (kPairItems + pair) * region;
+  const int fr = lane & 15, g = lane >> 4;
+  const int fsw = (fr >> 1) & 7;
+
+  // wave 0 of the pair: the item's K rows -> LDS, wave 1: its V rows (lanes past row L - 1 stay off)
+  {
+    char* dst = qb == 0 ? ks : vs;
+    const T* src0 = base + (qb == 0 ? C : 2 * C);
+    for (int jr = 0; jr * 8 < L; ++jr) {
+      const int row = jr * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      if (row < L)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src0 + (size_t)row * ld + chunk * 8),
+                                         (lds_ptr_t)(dst + jr * 1024), 16, 0, 0);
+    }
+  }
+  // Q fragments (B operand): Q[q0 + 16 mt + fr][32 kk + 8 g .. +8), as full lines (common.h, swap_piece)
+  vec8 qf[2][2];
+  {
+    const int sw_row = fr & 7, sw_col = (fr & 8) * 4 + g * 8;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      int ra = q0 + mt * 16 + sw_row, rb = ra + 8;
+      ra = ra < L ? ra : L - 1;
+      rb = rb < L ? rb : L - 1;
+      const vec8 pa = *reinterpret_cast<const vec8*>(base + (size_t)ra * ld + sw_col);
+      const vec8 pb = *reinterpret_cast<const vec8*>(base + (size_t)rb * ld + sw_col);
+      qf[mt][0] = swap_piece(pa, pb, true);
+      qf[mt][1] = swap_piece(pb, pa, false);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's LDS-DMA pieces have landed
+  __syncthreads();
+
+  // S^T[key][query] = K Q^T: K fragment as A operand, Q fragment as B operand
+  f32x4 sacc[4][2];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const vec8 kf = *reinterpret_cast<const vec8*>(ks + (kt * 16 + fr) * 128 + (((kk * 4 + g) ^ fsw) << 4));
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
+    }
+
+  // softmax over the keys of a query: 16 in-register values + the four 16-lane rows
+  vec8 pf[2][2];
+  float inv[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = sacc[kt][mt][i];
+        s = kt * 16 + 4 * g + i < L ? s : -1e30f;  // padded keys
+        sacc[kt][mt][i] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = rows16_max(mx);
+    const float nb = -mx * kLog2e;  // exp(s - mx) = 2^(s log2(e) - mx log2(e)): one FMA + v_exp_f32
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][mt][i], kLog2e, nb));
+        sacc[kt][mt][i] = p;
+        sum += p;
+      }
+    inv[mt] = 1.0f / rows16_sum(sum);
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      vec8 p8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p8[j] = to16<T>(sacc[2 * ks2 + (j >> 2)][mt][j & 3]);
+      pf[mt][ks2] = p8;
+    }
+  }
+
+  // O^T[d][query] = V^T P^T, V through the transpose read (key enumeration as in attention_kernel)
+  f32x4 oacc[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) oacc[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks2 = 0; ks2 < 2; ++ks2) {
+    const int row0 = 32 * ks2 + 4 * g + (fr >> 2);  // and row0 + 16: same swizzle
+    const int vsw = (row0 >> 1) & 7;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int c4 = (fr & 3) * 4;  // halves within the 16-column block dt
+      const char* p0 = vs + row0 * 128 + (((dt * 2 + (c4 >> 3)) ^ vsw) << 4) + (c4 & 4) * 2;
+      typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 16 * 128));
+      s16x8 both;
+      both[0] = lo[0]; both[1] = lo[1]; both[2] = lo[2]; both[3] = lo[3];
+      both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
+      const vec8 vf = __builtin_bit_cast(vec8, both);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ks2], oacc[dt][mt]);
+    }
+  }
+
+  // O -> this wave's share of the item's K rows (every wave of the block is past S and PV) -> full
+  // lines out.  Queries past L are not staged: their rows belong to the next region.
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 o = oacc[dt][mt];
+      if (q0 + mt * 16 + fr < L)
+        *reinterpret_cast<uint2*>(ks + (q0 + mt * 16 + fr) * 128 + (((dt * 2 + (g >> 1)) ^ fsw) << 4) + (g & 1) * 8) =
+            pack4<T>(o[0] * inv[mt], o[1] * inv[mt], o[2] * inv[mt], o[3] * inv[mt]);
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  T* obase = out + (size_t)img * L * C + h * kHeadDim;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = q0 + (lane >> 3) + 8 * i;
+    const uint4 v = *reinterpret_cast<const uint4*>(ks + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+    if (valid && row < L) *reinterpret_cast<uint4*>(obase + (size_t)row * C + (lane & 7) * 8) = v;
   }
 }
 
@@ -571,6 +766,8 @@ int g_attention_q32 = 1;
 int g_attention_coop = 1;
 // 1 = objects mode: the object token's attention rides on an idle wave of that kernel
 int g_attention_fuse_obj = 1;
+// L <= 64 without a causal mask: two waves share an item's K / V in LDS (attention_pair_kernel)
+int g_attention_pair = 1;
 
 template <typename T, int MT>
 static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, int causal,
@@ -584,6 +781,23 @@ static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, i
     hipLaunchKernelGGL((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
   else
     hipLaunchKernelGGL((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
+}
+
+template <typename T>
+static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, int heads, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = attention_pair_kernel<T>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, pair_lds_bytes(64));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int items = n * heads;
+  hipLaunchKernelGGL(kern, dim3((items + kPairItems - 1) / kPairItems), dim3(2 * kPairItems * 64),
+                     pair_lds_bytes(L), s, reinterpret_cast<const T*>(qkv), reinterpret_cast<T*>(out), L,
+                     heads, items);
+  return hipGetLastError();
 }
 
 bool attention_fuses_object_token(int L) {
@@ -613,6 +827,11 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
     else
       return hipErrorInvalidValue;
     return hipGetLastError();
+  }
+  if (g_attention_pair && g_attention_use_tr && L <= 64 && !causal && qkv_y == nullptr) {
+    if (dtype16 == DT_F16) return attn_pair_launch_t<f16_t>(qkv, out, n, L, heads, s);
+    if (dtype16 == DT_BF16) return attn_pair_launch_t<bf16_t>(qkv, out, n, L, heads, s);
+    return hipErrorInvalidValue;
   }
   if (dtype16 == DT_F16) {
     if (g_attention_q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, causal, s);

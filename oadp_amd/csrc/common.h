@@ -92,6 +92,34 @@ __device__ __forceinline__ float rows16_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Full-line global accesses from MFMA-fragment layouts.  In a 16x16x32 operand / accumulator-pair
+// layout lane (r = l & 15, g = l >> 4) owns the 16-B pieces g (k or column half 0) and 4 + g (half 1)
+// of row r, and a row is one 128-B line: an instruction per half touches 16 half lines, which the
+// vector memory path serves at about half the rate of 8 full lines (tools/ubench/store_bench.hip).
+// Instead lane (r, g) accesses piece A = (row r & 7, piece 4 (r >> 3) + g) and piece B = (row
+// 8 + (r & 7), same piece) — 8 rows x 128 B per instruction — and swaps one of them with lane r ^ 8:
+//     half 0 of the own row = swap_piece(A, B, true),   half 1 = swap_piece(B, A, false)   (loads)
+//     A = swap_piece(half 0, half 1, true),              B = swap_piece(half 1, half 0, false) (stores)
+// Row-octet exchange of 16-byte pieces between lanes r and r ^ 8 of each 16-lane row.  For the
+// lanes selected by `low` (true: rows 8-15, false: rows 0-7) the result is the partner's `theirs`;
+// the other lanes keep `mine`.  One bank-masked row_ror:8 DPP move per register.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <typename V>
+__device__ __forceinline__ V swap_piece(V mine, V theirs, bool take_in_upper_rows) {
+  static_assert(sizeof(V) == 16, "16-byte pieces");
+  u32x4_t m, t, o;
+  __builtin_memcpy(&m, &mine, 16);
+  __builtin_memcpy(&t, &theirs, 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = take_in_upper_rows
+               ? (unsigned)__builtin_amdgcn_update_dpp((int)m[i], (int)t[i], 0x128, 0xF, 0xC, false)
+               : (unsigned)__builtin_amdgcn_update_dpp((int)m[i], (int)t[i], 0x128, 0xF, 0x3, false);
+  V out;
+  __builtin_memcpy(&out, &o, 16);
+  return out;
+}
+
 // QuickGELU (OpenAI CLIP): x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)).
 // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division: the result is rounded to 16 bits
 // right after, and the c_fc epilogue evaluates this 80 times per lane per tile.

@@ -159,26 +159,6 @@ struct EpiLds {
   static constexpr int kBytes = 2048 + 160 * 8;
 };
 
-// Row-octet exchange of 16-byte pieces between lanes r and r ^ 8 of each 16-lane row.  For the
-// lanes selected by `low` (true: rows 8-15, false: rows 0-7) the result is the partner's `theirs`;
-// the other lanes keep `mine`.  One bank-masked row_ror:8 DPP move per register.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <typename V>
-__device__ __forceinline__ V swap_piece(V mine, V theirs, bool take_in_upper_rows) {
-  static_assert(sizeof(V) == 16, "16-byte pieces");
-  u32x4_t m, t, o;
-  __builtin_memcpy(&m, &mine, 16);
-  __builtin_memcpy(&t, &theirs, 16);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    o[i] = take_in_upper_rows
-               ? (unsigned)__builtin_amdgcn_update_dpp((int)m[i], (int)t[i], 0x128, 0xF, 0xC, false)
-               : (unsigned)__builtin_amdgcn_update_dpp((int)m[i], (int)t[i], 0x128, 0xF, 0x3, false);
-  V out;
-  __builtin_memcpy(&out, &o, 16);
-  return out;
-}
-
 template <bool ELDS>
 __device__ __forceinline__ float4 epi_vec4(const float* gptr, int n, const char* elds, int off, int lc) {
   if constexpr (ELDS)

@@ -166,10 +166,12 @@ def _attention_ref(qkv, n, l, heads):
     return (p @ v).permute(0, 2, 1, 3).reshape(n * l, c)
 
 
-@pytest.mark.parametrize('use_tr', [0, 1, 2, 3, 7])  # bit 2: K / V shared through LDS for l > 64
+# bit 2: K / V shared through LDS for l > 64; bit 4: persistent loader-wave kernel for l <= 64
+@pytest.mark.parametrize('use_tr', [0, 1, 2, 3, 7, 31])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('n,l,heads', [(1, 50, 2), (3, 50, 12), (2, 197, 2), (5, 64, 3), (2, 17, 1),
-                                       (1, 130, 1), (3, 77, 8), (2, 65, 1), (1, 300, 2)])
+                                       (1, 130, 1), (3, 77, 8), (2, 65, 1), (1, 300, 2), (1, 1, 1),
+                                       (64, 50, 12), (7, 33, 5)])
 def test_attention(lib, cuda, dtype, n, l, heads, use_tr):
     g = torch.Generator(device='cpu').manual_seed(n * 100 + l + heads)
     qkv = torch.randn(n * l, 3 * heads * 64, generator=g)
@@ -182,7 +184,7 @@ def test_attention(lib, cuda, dtype, n, l, heads, use_tr):
         assert rc == 0
         torch.cuda.synchronize()
     finally:
-        lib.oake_debug_set_attention_variant(15)
+        lib.oake_debug_set_attention_variant(31)
     ref = _attention_ref(qkv, n, l, heads)
     tol = 3e-3 if dtype == torch.float16 else 2e-2
     torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)

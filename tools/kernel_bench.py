@@ -18,11 +18,11 @@ def timeit(fn, reps=30):
 n, L, H = 256, 50, 12
 qkv = torch.randn(n * L, 3 * H * 64, device=dev).half()
 out = torch.empty(n * L, H * 64, device=dev, dtype=torch.float16)
-for v in (0, 1, 2, 3):
+for v in (0, 1, 2, 3, 31):
     lib.oake_debug_set_attention_variant(v)
     us = timeit(lambda: lib.oake_debug_attention(qkv.data_ptr(), out.data_ptr(), n, L, H, 1, s))
     print(f'attention variant {v}: {us:.1f} us  ({(qkv.numel()+out.numel())*2/us/1e6:.2f} TB/s)')
-lib.oake_debug_set_attention_variant(15)
+lib.oake_debug_set_attention_variant(31)
 x = torch.randn(n * L, 768, device=dev); g = torch.ones(768, device=dev); b = torch.zeros(768, device=dev)
 y = torch.empty(n * L, 768, device=dev, dtype=torch.float16)
 us = timeit(lambda: lib.oake_debug_layernorm(x.data_ptr(), 0, g.data_ptr(), b.data_ptr(), y.data_ptr(), n * L, 768, 1, s))
