@@ -211,8 +211,20 @@ class VisionTransformer:
         dev = image_u8.device.index if image_u8.device.index is not None else torch.cuda.current_device()
         return image_u8.contiguous(), dev
 
+    def _crop_out(self, out: torch.Tensor | None, k: int, n: int, out_dtype: torch.dtype,
+                  device: torch.device) -> torch.Tensor:
+        """The [k,3,n,n] destination of a crop call: freshly allocated, or the caller's slice of a
+        larger batch tensor (a sweep fills one tensor per flush instead of concatenating hundreds)."""
+        if out is None:
+            return torch.empty((k, 3, n, n), dtype=out_dtype, device=device)
+        if (tuple(out.shape) != (k, 3, n, n) or out.dtype != out_dtype or out.device != device
+                or not out.is_contiguous()):
+            raise ValueError(f'out must be a contiguous {out_dtype} tensor of shape {(k, 3, n, n)} on {device}')
+        return out
+
     def crop_resize_normalize(self, image_u8: torch.Tensor, boxes, *, squash: bool = False,
-                              out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                              out_dtype: torch.dtype = torch.float32,
+                              out: torch.Tensor | None = None) -> torch.Tensor:
         """``torch.stack([preprocess(image.crop(box)) for box in boxes])`` on the device, bit-exact
         with Pillow + torchvision (Image.crop, Resize(n, BICUBIC), CenterCrop, ToTensor, Normalize).
         ``boxes``: [k,4] float (x1,y1,x2,y2), any device."""
@@ -220,7 +232,7 @@ class VisionTransformer:
         image_u8, dev = self._image_args(image_u8)
         boxes = torch.as_tensor(boxes, dtype=torch.float32).reshape(-1, 4).cpu().contiguous()
         k, n = boxes.shape[0], self.input_resolution
-        out = torch.empty((k, 3, n, n), dtype=out_dtype, device=image_u8.device)
+        out = self._crop_out(out, k, n, out_dtype, image_u8.device)
         if k == 0:
             return out
         with torch.cuda.device(dev):
@@ -278,28 +290,39 @@ class VisionTransformer:
             _lib.check(self._lib, h, rc, 'oake_decode_jpeg')
         return out
 
-    def decode_jpeg_batch(self, datas: list[bytes], device: torch.device | None = None, *,
+    def decode_jpeg_batch(self, datas: list, device: torch.device | None = None, *,
                           threads: int = 16) -> list[torch.Tensor | None]:
         """``decode_jpeg`` for many files in one native call: the Huffman passes run on ``threads``
-        host threads inside the library (no GIL), the GPU half on the current stream.  Files outside
-        the supported subset come back as ``None`` (decode those with PIL)."""
+        host threads inside the library (no GIL), the GPU half on the current stream.  ``datas``:
+        ``bytes`` objects or 1-D uint8 CPU tensors (read in place, no copy).  The images are views of
+        one device allocation per call.  Files outside the supported subset come back as ``None``
+        (decode those with PIL)."""
         dev = torch.device(device).index if device is not None else None
         dev = torch.cuda.current_device() if dev is None else dev
         n = len(datas)
         if n == 0:
             return []
-        bufs = [(C.c_uint8 * len(d)).from_buffer_copy(d) for d in datas]
-        sizes = []
-        for b, d in zip(bufs, datas):
-            hh, ww = C.c_int(0), C.c_int(0)
-            ok = self._lib.oake_jpeg_info(b, len(d), C.byref(hh), C.byref(ww), None) == _lib.OAKE_OK
+        ptrs, lens = (C.c_void_p * n)(), (C.c_size_t * n)()
+        for i, d in enumerate(datas):
+            if isinstance(d, torch.Tensor):
+                if d.dtype != torch.uint8 or d.dim() != 1 or d.is_cuda or not d.is_contiguous():
+                    raise ValueError('JPEG data tensors must be contiguous 1-D uint8 CPU tensors')
+                ptrs[i], lens[i] = d.data_ptr(), d.numel()
+            else:
+                ptrs[i], lens[i] = C.cast(C.c_char_p(d), C.c_void_p), len(d)  # borrows d's buffer
+        sizes, offsets, total = [], [], 0
+        hh, ww = C.c_int(0), C.c_int(0)
+        for i in range(n):
+            ok = self._lib.oake_jpeg_info(ptrs[i], lens[i], C.byref(hh), C.byref(ww), None) == _lib.OAKE_OK
             sizes.append((hh.value, ww.value) if ok else None)
-        outs = [torch.empty((s[0], s[1], 3), dtype=torch.uint8, device=torch.device('cuda', dev)) if s else None
-                for s in sizes]
-        ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
-        lens = (C.c_size_t * n)(*[len(d) for d in datas])
-        optr = (C.c_void_p * n)(*[C.c_void_p(o.data_ptr()) if o is not None else None for o in outs])
-        caps = (C.c_size_t * n)(*[o.numel() if o is not None else 0 for o in outs])
+            offsets.append(total)
+            if ok:
+                total += (hh.value * ww.value * 3 + 255) & ~255
+        arena = torch.empty(max(total, 1), dtype=torch.uint8, device=torch.device('cuda', dev))
+        outs = [arena[o:o + s[0] * s[1] * 3].view(s[0], s[1], 3) if s else None for s, o in zip(sizes, offsets)]
+        base = arena.data_ptr()
+        optr = (C.c_void_p * n)(*[base + o if s else None for s, o in zip(sizes, offsets)])
+        caps = (C.c_size_t * n)(*[s[0] * s[1] * 3 if s else 0 for s in sizes])
         status = (C.c_int * n)()
         with torch.cuda.device(dev):
             h = self._ensure_handle(dev)
@@ -309,13 +332,14 @@ class VisionTransformer:
         return [o if status[i] == _lib.OAKE_OK else None for i, o in enumerate(outs)]
 
     def crop_normalize(self, image_u8: torch.Tensor, boxes_xyxy, *,
-                       out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                       out_dtype: torch.dtype = torch.float32,
+                       out: torch.Tensor | None = None) -> torch.Tensor:
         """Exact-size (n x n) integer crops + ToTensor + Normalize (blocks of one pyramid level)."""
         from .preprocess import CLIP_MEAN, CLIP_STD
         image_u8, dev = self._image_args(image_u8)
         boxes = torch.as_tensor(boxes_xyxy, dtype=torch.int32).reshape(-1, 4).to(image_u8.device).contiguous()
         k, n = boxes.shape[0], self.input_resolution
-        out = torch.empty((k, 3, n, n), dtype=out_dtype, device=image_u8.device)
+        out = self._crop_out(out, k, n, out_dtype, image_u8.device)
         if k == 0:
             return out
         with torch.cuda.device(dev):

@@ -26,6 +26,7 @@ import torch.utils.data.distributed
 
 from ..config import Config, parse_override
 from ..store import Store, get_local_rank, get_rank, get_world_size
+from . import fastsave
 
 
 class Batch(Protocol):
@@ -160,7 +161,12 @@ def atomic_save(obj: Any, path: pathlib.Path) -> None:
     """torch.save via tmp + rename: same visible contract as oadp/oake/base.py:112, but a killed
     run cannot leave a truncated file (what ``auto_fix`` exists to repair)."""
     tmp = path.with_name(path.name + f'.tmp{os.getpid()}')
-    torch.save(obj, tmp)
+    data = fastsave.SAVER.dumps(obj)  # the archive torch.save would write (fastsave.py), or None
+    if data is None:
+        torch.save(obj, tmp)
+    else:
+        with open(tmp, 'wb') as f:
+            f.write(data)
     os.replace(tmp, path)
 
 
@@ -304,12 +310,12 @@ class BaseValidator(ABC, Generic[T]):
         out: list[torch.Tensor | None] = [None] * len(ts)
         enc = [i for i, t in enumerate(ts) if t.dim() == 1]
         if enc:
-            datas = [ts[i].numpy().tobytes() for i in enc]
-            decoded = self._model.visual.decode_jpeg_batch(datas, self._device, threads=self._decode_threads)
-            for i, d, img in zip(enc, datas, decoded):
+            decoded = self._model.visual.decode_jpeg_batch([ts[i] for i in enc], self._device,
+                                                           threads=self._decode_threads)
+            for i, img in zip(enc, decoded):
                 if img is None:  # entropy segment the device decoder rejects: PIL has the final word
                     import io
-                    img = image_to_u8(PIL.Image.open(io.BytesIO(d))).to(self._device)
+                    img = image_to_u8(PIL.Image.open(io.BytesIO(ts[i].numpy().tobytes()))).to(self._device)
                 out[i] = img
         for i, t in enumerate(ts):
             if out[i] is None:

@@ -108,30 +108,38 @@ class Validator(BaseValidator[Batch]):
     def _n_crops(self, batch: Batch) -> int:
         return batch.bboxes.shape[0]
 
-    def _device_blocks(self, image_u8: torch.Tensor) -> torch.Tensor:
-        """Blocks of one image on the GPU: block 0 = preprocess(whole image); then per pyramid level
-        exact 224x224 crops of the level image, levels chained by Pillow-exact resizes."""
+    def _device_blocks(self, image_u8: torch.Tensor, out: torch.Tensor) -> None:
+        """Blocks of one image on the GPU, written into ``out`` [k,3,r,r]: block 0 =
+        preprocess(whole image); then per pyramid level exact 224x224 crops of the level image,
+        levels chained by Pillow-exact resizes."""
         ds = self._dataloader.dataset
         v = self._model.visual
         level = image_u8
         h, w = level.shape[:2]
-        out = [v.crop_resize_normalize(level, [(0, 0, w, h)], out_dtype=torch.float16)]
-        r = ds._r
+        v.crop_resize_normalize(level, [(0, 0, w, h)], out_dtype=torch.float16, out=out[0:1])
+        r, i = ds._r, 1
         while True:
             tiles = list(itertools.product(ds._partition(w), ds._partition(h)))
             if not tiles:
                 break
-            out.append(v.crop_normalize(level, [(x, y, x + r, y + r) for x, y in tiles],
-                                        out_dtype=torch.float16))
+            v.crop_normalize(level, [(x, y, x + r, y + r) for x, y in tiles], out_dtype=torch.float16,
+                             out=out[i:i + len(tiles)])
+            i += len(tiles)
             w, h = int(w / ds._rescale), int(h / ds._rescale)
             level = v.resize_u8(level, (w, h))
-        return torch.cat(out)
+        if i != out.shape[0]:
+            raise RuntimeError(f'{i} blocks cut, {out.shape[0]} expected from the dataset\'s bboxes')
 
     def _encode(self, batches: list[Batch]) -> list[dict]:
         # reference _run_iter (blocks.py:125-135), crops of several images in one encoder pass
         if batches[0].blocks.dtype == torch.uint8:
-            blocks = torch.cat([self._device_blocks(im) for im in self._images_u8([b.blocks for b in batches])])
             counts = [b.bboxes.shape[0] for b in batches]
+            r = self._dataloader.dataset._r
+            blocks = torch.empty((sum(counts), 3, r, r), dtype=torch.float16, device=self._device)
+            i = 0
+            for im, k in zip(self._images_u8([b.blocks for b in batches]), counts):
+                self._device_blocks(im, blocks[i:i + k])
+                i += k
         else:
             blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
             counts = [b.blocks.shape[0] for b in batches]

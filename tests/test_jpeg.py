@@ -177,6 +177,45 @@ def test_device_decode_batch(cuda):
         for d, o in zip(datas, outs):
             if o is not None:
                 assert np.array_equal(o.cpu().numpy(), _pil(d))
+    # file bytes as 1-D uint8 tensors (what the dataset hands over) are read in place; the images of a
+    # call are views of one allocation, 256-byte aligned
+    import torch
+    mixed = [torch.frombuffer(bytearray(d), dtype=torch.uint8) if i % 2 else d for i, d in enumerate(datas)]
+    outs = model.visual.decode_jpeg_batch(mixed, threads=8)
+    for d, o in zip(datas, outs):
+        if o is not None:
+            assert o.data_ptr() % 256 == 0 and np.array_equal(o.cpu().numpy(), _pil(d))
+    with pytest.raises(ValueError):
+        model.visual.decode_jpeg_batch([torch.zeros(4, 4, dtype=torch.uint8)])
+    assert model.visual.decode_jpeg_batch([b'garbage']) == [None] and model.visual.decode_jpeg_batch([]) == []
+
+
+@pytest.mark.gpu
+def test_crops_into_preallocated_batch(cuda):
+    """out=: the sweep fills one [N,3,n,n] tensor per flush; same pixels as the allocating call."""
+    import torch
+    from oadp_amd import clip
+    from oadp_amd.weights import synthetic_state_dict
+    from tests._synth import TINY
+    model, _ = clip.load(synthetic_state_dict(**TINY), max_batch=2)
+    v = model.visual
+    n = v.input_resolution
+    img = torch.from_numpy(_synth(97, 143, 'noise', seed=5)).to(cuda)
+    boxes = [(0, 0, 143, 97), (10.5, 3.2, 80.1, 60.0), (-5, -5, 40, 40)]
+    want = v.crop_resize_normalize(img, boxes, out_dtype=torch.float16)
+    batch = torch.zeros((5, 3, n, n), dtype=torch.float16, device=cuda)
+    got = v.crop_resize_normalize(img, boxes, out_dtype=torch.float16, out=batch[1:4])
+    assert got.data_ptr() == batch[1:4].data_ptr() and torch.equal(batch[1:4], want)
+    assert not batch[0].any() and not batch[4].any()
+    tiles = [(0, 0, n, n), (143 - n, 97 - n, 143, 97)] if n <= 97 else []
+    if tiles:
+        want = v.crop_normalize(img, tiles, out_dtype=torch.float16)
+        v.crop_normalize(img, tiles, out_dtype=torch.float16, out=batch[0:2])
+        assert torch.equal(batch[0:2], want)
+    with pytest.raises(ValueError):
+        v.crop_resize_normalize(img, boxes, out_dtype=torch.float16, out=batch[0:2])
+    with pytest.raises(ValueError):
+        v.crop_resize_normalize(img, boxes, out_dtype=torch.float32, out=batch[1:4])
 
 
 @pytest.mark.gpu
