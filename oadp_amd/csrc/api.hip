@@ -25,6 +25,7 @@
 #include "kernels.h"
 
 namespace oake {
+hipEvent_t g_launch_start = nullptr, g_launch_stop = nullptr;  // common.h, OAKE_LAUNCH
 extern int g_attention_use_tr;
 extern int g_attention_q32;
 extern int g_attention_coop;
@@ -183,6 +184,23 @@ int prof_begin(oake_handle* h, const char* name, double flops, double bytes, hip
 void prof_end(oake_handle* h, int idx, hipStream_t s) {
   if (idx >= 0) (void)hipEventRecord(h->pending[idx].b, s);
 }
+// Single-kernel launches (GEMMs, attention): the kernel's own begin / end stamps, see common.h
+int prof_begin_kernel(oake_handle* h, const char* name, double flops, double bytes) {
+  if (!h->prof) return -1;
+  const int sl = slot_of(h, name);
+  h->slots[sl].flops += flops;
+  h->slots[sl].bytes += bytes;
+  h->slots[sl].launches += 1;
+  PendingEvt p{sl, get_evt(h), get_evt(h)};
+  h->pending.push_back(p);
+  oake::g_launch_start = p.a;
+  oake::g_launch_stop = p.b;
+  return (int)h->pending.size() - 1;
+}
+void prof_end_kernel() {
+  oake::g_launch_start = nullptr;
+  oake::g_launch_stop = nullptr;
+}
 
 void prof_collect(oake_handle* h) {
   for (auto& p : h->pending) {
@@ -194,6 +212,17 @@ void prof_collect(oake_handle* h) {
   }
   h->pending.clear();
 }
+
+#define RUNK(h, s, name, flops, bytes, call)                \
+  do {                                                      \
+    (void)prof_begin_kernel(h, name, flops, bytes);         \
+    hipError_t _e = (call);                                 \
+    prof_end_kernel();                                      \
+    if (_e != hipSuccess) {                                 \
+      (h)->err = std::string(name) + ": " + hipGetErrorString(_e); \
+      return OAKE_ERR_HIP;                                  \
+    }                                                       \
+  } while (0)
 
 #define RUN(h, s, name, flops, bytes, call)                 \
   do {                                                      \
@@ -597,7 +626,7 @@ int gemm(oake_handle* h, hipStream_t s, const char* name, int epi, const void* A
   const char* xb = reinterpret_cast<const char*>(h->x);
   const bool to_resid = out == xb + row0 * (size_t)ldo * (h->xdt == DT_F32 ? 4 : 2);
   if (h->stat_fused && epi == EPI_RESID16 && to_resid) a.rowpart_out = part;
-  RUN(h, s, name, 2.0 * M * N * K, 0.0, launch_gemm(h->dt16, epi, a, s));
+  RUNK(h, s, name, 2.0 * M * N * K, 0.0, launch_gemm(h->dt16, epi, a, s));
   if (a.rowpart_out) h->nparts = N / 64;
   return OAKE_OK;
 }
@@ -613,7 +642,7 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   GemmArgs a{};
   a.A = h->a_patch; a.W = h->conv_w; a.bias = nullptr; a.out = h->x;
   a.M = nb * h->p2; a.N = C; a.K = h->kpatch; a.ldo = C; a.pos = h->pos; a.P2 = h->p2; a.L = L;
-  RUN(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0,
+  RUNK(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0,
       launch_gemm(h->dt16, h->xdt == DT_F32 ? EPI_PATCH : EPI_PATCH16, a, s));
   // 16-bit residual stream + every main-stream GEMM on the persistent kernel: LayerNorm statistics
   // are produced by the kernel that writes x (here: slot 0) and consumed by the next GEMM
@@ -692,7 +721,7 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   // attention + out_proj + MLP of the main token stream (qkv already computed)
   const int C = h->cfg.width, L = h->cur_len, T = nb * L;
   const int Lp = ((L + 63) / 64) * 64;
-  RUN(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
+  RUNK(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
       launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s));
   return mlp_rows(h, s, w, 0, T, "");
 }
@@ -957,11 +986,11 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       // idle wave of the main stream's attention launch when there is one, else its own kernel
       const bool fuse = !last && attention_fuses_object_token(L);
       if (!fuse)
-        RUN(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
+        RUNK(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
             launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s));
       if (!last) {
         const int Lp = ((L + 63) / 64) * 64;
-        RUN(h, s, "attention", 4.0 * nb * c.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
+        RUNK(h, s, "attention", 4.0 * nb * c.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
             launch_attention(h->dt16, h->qkv, h->att, nb, L, c.heads, 0, s, fuse ? qkv_y : nullptr,
                              fuse ? masks : nullptr, mask_dtype, fuse ? att_y : nullptr));
         if ((rc = mlp_rows(h, s, w, 0, T + nb, ""))) return rc;

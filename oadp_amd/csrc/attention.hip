@@ -778,9 +778,9 @@ static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, i
   const T* in = reinterpret_cast<const T*>(qkv);
   T* o = reinterpret_cast<T*>(out);
   if (g_attention_use_tr)
-    hipLaunchKernelGGL((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
+    OAKE_LAUNCH((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
   else
-    hipLaunchKernelGGL((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
+    OAKE_LAUNCH((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
 }
 
 template <typename T>
@@ -794,7 +794,7 @@ static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, i
     attr_set = true;
   }
   const int items = n * heads;
-  hipLaunchKernelGGL(kern, dim3((items + kPairItems - 1) / kPairItems), dim3(2 * kPairItems * 64),
+  OAKE_LAUNCH(kern, dim3((items + kPairItems - 1) / kPairItems), dim3(2 * kPairItems * 64),
                      pair_lds_bytes(L), s, reinterpret_cast<const T*>(qkv), reinterpret_cast<T*>(out), L,
                      heads, items);
   return hipGetLastError();
@@ -819,10 +819,10 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
     const dim3 grid(n * heads * QG), blk(256);
     const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
     if (dtype16 == DT_F16)
-      hipLaunchKernelGGL(attention_coop_kernel<f16_t>, grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
+      OAKE_LAUNCH(attention_coop_kernel<f16_t>, grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
                          reinterpret_cast<f16_t*>(out), L, heads, QG, causal, obj);
     else if (dtype16 == DT_BF16)
-      hipLaunchKernelGGL(attention_coop_kernel<bf16_t>, grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
+      OAKE_LAUNCH(attention_coop_kernel<bf16_t>, grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
                          reinterpret_cast<bf16_t*>(out), L, heads, QG, causal, obj);
     else
       return hipErrorInvalidValue;
@@ -851,12 +851,12 @@ static hipError_t obj_attn_t(const void* qkv_x, const void* qkv_y, const void* m
   const int total = n * heads;
   const dim3 g((total + 3) / 4), b(256);
   if (mask_dtype == DT_F32)
-    hipLaunchKernelGGL((object_attention_kernel<T, float>), g, b, 0, s,
+    OAKE_LAUNCH((object_attention_kernel<T, float>), g, b, 0, s,
                        reinterpret_cast<const T*>(qkv_x), reinterpret_cast<const T*>(qkv_y),
                        reinterpret_cast<const float*>(mask), reinterpret_cast<T*>(out), L, heads,
                        total);
   else if (mask_dtype == DT_F16)
-    hipLaunchKernelGGL((object_attention_kernel<T, f16_t>), g, b, 0, s,
+    OAKE_LAUNCH((object_attention_kernel<T, f16_t>), g, b, 0, s,
                        reinterpret_cast<const T*>(qkv_x), reinterpret_cast<const T*>(qkv_y),
                        reinterpret_cast<const f16_t*>(mask), reinterpret_cast<T*>(out), L, heads,
                        total);
@@ -876,7 +876,7 @@ hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* q
 }
 
 hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s) {
-  hipLaunchKernelGGL(tr_read_probe_kernel, dim3(1), dim3(64), 0, s, in, out);
+  OAKE_LAUNCH(tr_read_probe_kernel, dim3(1), dim3(64), 0, s, in, out);
   return hipGetLastError();
 }
 

@@ -954,7 +954,7 @@ hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
                reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
                a.nparts, 1.0f / (float)a.K};
-  hipLaunchKernelGGL(kern, dim3(tmap.nwg), dim3(WM * WN * 64), lds, s,
+  OAKE_LAUNCH(kern, dim3(tmap.nwg), dim3(WM * WN * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
   return hipGetLastError();
@@ -989,7 +989,7 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
                reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
                a.nparts, 1.0f / (float)a.K};
-  hipLaunchKernelGGL(kern, dim3(grid), dim3((WM * WN + 4) * 64), lds, s,
+  OAKE_LAUNCH(kern, dim3(grid), dim3((WM * WN + 4) * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
   return hipGetLastError();

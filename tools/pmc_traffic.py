@@ -26,3 +26,14 @@ for k in fetch:
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:12]:
     print(f"{v['hbm_bytes_per_launch']/1e6:9.1f} MB/launch  read {v['hbm_read_bytes_corrected']/1e6:8.1f}  write {v['hbm_write_bytes']/1e6:8.1f}  n={v['launches_sampled']:4d}  {k[:110]}")
+
+# bench.py looks the dominant kernel up by its profiler name: profiles/hbm_traffic.json = the records
+# above keyed by those names (the residual GEMM instantiation serves two call sites and is left out)
+if len(sys.argv) > 4:
+    names = {'im2col_kernel': 'im2col', 'gemm_pp_kernelIDF16_Li6E': 'gemm_conv1', 'gemm_pp_kernelIDF16_Li7E': 'gemm_qkv',
+             'gemm_pp_kernelIDF16_Li8E': 'gemm_c_fc', 'attention_pair_kernelIDF16_': 'attention',
+             'embed_ln_pre_kernel': 'embed_ln_pre'}
+    src = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) of `python bench.py '
+           '--steps 3 --warmup 2`; FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 correction, KiB units')
+    json.dump({n: dict(v, kernel=k, source=src) for k, v in out.items() for p, n in names.items() if p in k},
+              open(sys.argv[4], 'w'), indent=1)
