@@ -137,6 +137,17 @@ def main() -> None:
             if rec:
                 roofline['traffic'] = rec['hbm_bytes_per_launch']
                 roofline['traffic_unit'] = 'bytes/launch (PMC, profiles/hbm_traffic.json)'
+        # the committed rocprofv3 --kernel-trace --stats summary of this same command, for comparison
+        # (kernel begin/end stamps of consecutive launches include the hand-over between kernels, which
+        # rocprofv3's per-dispatch interval does not: expect the live number a few % higher)
+        spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_rocprofv3_kernel_stats.csv')
+        rec = (json.load(open(tpath)).get(dom['name']) or {}) if os.path.exists(tpath) else {}
+        if os.path.exists(spath) and rec.get('kernel') and args.batch == 256 and args.dtype == 'f16':
+            import csv
+            for row in csv.DictReader(open(spath)):
+                if row['Name'] == rec['kernel']:
+                    roofline['avg_launch_us_rocprofv3'] = round(float(row['AverageNs']) / 1e3, 2)
+                    roofline['rocprofv3_summary'] = 'profiles/r01_rocprofv3_kernel_stats.csv'
         tot_ms = sum(p['total_ms'] for p in prof)
         kernels = {p['name']: {'ms_per_step': round(p['total_ms'] / 3, 4),
                                'share': round(p['total_ms'] / tot_ms, 4),
