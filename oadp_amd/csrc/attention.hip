@@ -24,6 +24,7 @@ namespace oake {
 
 namespace {
 
+constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kVStride = 72;                       // halves per V row in LDS (64 + 8 pad = 144 B)
 constexpr int kVBytesPerWave = 64 * kVStride * 2;  // 9216
 
@@ -263,7 +264,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
 //     then loads, computes and stores in step and nothing overlaps; 1 item 17.3; attention_kernel 18.0.)
 //   * O leaves through the wave's half of the K rows (after a second barrier): 8 rows x 128 B per store.
 constexpr int kPairItems = 2;
-constexpr float kLog2e = 1.4426950408889634f;
 
 __host__ __device__ constexpr int pair_lds_bytes(int L) { return (2 * kPairItems * L + (64 - L)) * 128; }
 
@@ -655,12 +655,13 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
         mx = rows16_max(mx);
         const float m_new = fmaxf(m_run[mt], mx);
         const float alpha = __expf(m_run[mt] - m_new);
+        const float nb = -m_new * kLog2e;  // exp(s - m) = 2^(s log2(e) - m log2(e)): one FMA + v_exp_f32
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = __expf(sacc[kt][mt][r] - m_new);
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][mt][r], kLog2e, nb));
             sacc[kt][mt][r] = p;
             sum += p;
           }
@@ -729,18 +730,27 @@ __global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict
     }
     return;
   }
+  // O through LDS (the K / V chunk buffers are free after the loop's last barrier; wave w takes 32 rows
+  // of ks or vs) so that it leaves as 8 rows x 128 B per store instead of 16 quarter lines
   T* obase = out + (size_t)img * L * C + h * kHeadDim;
+  T* stage = ((wid & 2) ? vs : ks) + (wid & 1) * 32 * kVStride;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int q = q0 + mt * 16 + fr;
-    if (q >= L) continue;
     const float inv = 1.0f / l_run[mt];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const f32x4 o = oacc[dt][mt];
-      *reinterpret_cast<uint2*>(obase + (size_t)q * C + dt * 16 + 4 * g) =
+      *reinterpret_cast<uint2*>(stage + (mt * 16 + fr) * kVStride + dt * 16 + 4 * g) =
           pack4<T>(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
     }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 2 * MT; ++i) {
+    const int row = (lane >> 3) + 8 * i;
+    const uint4 v = *reinterpret_cast<const uint4*>(stage + row * kVStride + (lane & 7) * 8);
+    if (q0 + row < L) *reinterpret_cast<uint4*>(obase + (size_t)(q0 + row) * C + (lane & 7) * 8) = v;
   }
 }
 
