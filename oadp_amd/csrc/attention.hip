@@ -513,7 +513,7 @@ struct ObjArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void attention_coop_kernel(const T* __restrict__ qkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_coop_kernel(const T* __restrict__ qkv,
                                                              T* __restrict__ out, int L, int H, int QG,
                                                              int causal, ObjArgs obj) {
   typedef typename T16<T>::vec8 vec8;
