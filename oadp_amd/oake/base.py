@@ -170,6 +170,19 @@ def atomic_save(obj: Any, path: pathlib.Path) -> None:
     os.replace(tmp, path)
 
 
+class _HostCopy:
+    """A device -> host copy in flight: ``get()`` waits for it and returns the host tensor."""
+
+    def __init__(self, tensor: torch.Tensor, event: 'torch.cuda.Event | None') -> None:
+        self._tensor, self._event = tensor, event
+
+    def get(self) -> torch.Tensor:
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        return self._tensor
+
+
 class AsyncWriter:
     """Background ``atomic_save``: the reference writes one small file per
     image synchronously on the thread that also drives the GPU (oadp/oake/base.py:112); at 10^4-10^5
@@ -278,6 +291,9 @@ class BaseValidator(ABC, Generic[T]):
         self._decode_threads = decode_threads
         self._prefetch = prefetch
         self._writer: AsyncWriter | None = None
+        self._inflight: tuple[list, Any] | None = None   # the flush whose results are still on the GPU
+        self._host_bufs: list[torch.Tensor | None] = [None, None]
+        self._host_slot = 0
         self._dataloader = self._build_dataloader(Config(dataloader))
 
     # -- reference surface ----------------------------------------------------------------------
@@ -322,14 +338,49 @@ class BaseValidator(ABC, Generic[T]):
                 out[i] = t.to(self._device, non_blocking=True)
         return out
 
+    def _to_host(self, t: torch.Tensor) -> '_HostCopy':
+        """Start the device -> host copy of an encoder output without waiting for it (``_encode`` may
+        return a closure that calls ``.get()``: see ``_flush``).  Two pinned buffers alternate, so a
+        result must be cloned out of the returned tensor before the flush after next starts its copy."""
+        if not t.is_cuda:
+            return _HostCopy(t, None)
+        n, slot = t.numel(), self._host_slot
+        self._host_slot ^= 1
+        buf = self._host_bufs[slot]
+        if buf is None or buf.numel() < n or buf.dtype != t.dtype:
+            buf = self._host_bufs[slot] = torch.empty(max(n, 1), dtype=t.dtype, pin_memory=True)
+        dst = buf[:n].view(t.shape)
+        dst.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _HostCopy(dst, ev)
+
+    def _submit(self, batches: list[T], results: list) -> None:
+        assert self._writer is not None
+        for batch, result in zip(batches, results):
+            self._writer.submit(result, batch.output)
+            self.counters.images += 1
+
+    def _finish_inflight(self) -> None:
+        if self._inflight is not None:
+            (batches, finish), self._inflight = self._inflight, None
+            self._submit(batches, finish())
+
     def _flush(self, pending: list[T]) -> None:
+        """Encode a flush and hand its results to the writer.  ``_encode`` returns the results, or — on
+        the GPU — a closure that produces them once the device has finished: then the flush stays in
+        flight while the host decodes and cuts the crops of the next one, and is written out when that
+        one has been launched (one flush of look-ahead; file order is unchanged)."""
         if not pending:
             return
         results = self._encode(pending)
-        assert self._writer is not None
-        for batch, result in zip(pending, results):
-            self._writer.submit(result, batch.output)
-            self.counters.images += 1
+        if callable(results):
+            previous, self._inflight = self._inflight, (list(pending), results)
+            if previous is not None:
+                self._submit(previous[0], previous[1]())
+        else:
+            self._finish_inflight()
+            self._submit(pending, results)
         pending.clear()
 
     def run(self) -> Counters:
@@ -405,6 +456,7 @@ class BaseValidator(ABC, Generic[T]):
                       f'images {self.counters.images} crops {self.counters.crops}', flush=True)
         self.counters.crops += crops
         self._flush(pending)
+        self._finish_inflight()
 
     @classmethod
     def main(cls, argv: list[str] | None = None) -> None:

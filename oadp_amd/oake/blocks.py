@@ -130,7 +130,7 @@ class Validator(BaseValidator[Batch]):
         if i != out.shape[0]:
             raise RuntimeError(f'{i} blocks cut, {out.shape[0]} expected from the dataset\'s bboxes')
 
-    def _encode(self, batches: list[Batch]) -> list[dict]:
+    def _encode(self, batches: list[Batch]):
         # reference _run_iter (blocks.py:125-135), crops of several images in one encoder pass
         if batches[0].blocks.dtype == torch.uint8:
             counts = [b.bboxes.shape[0] for b in batches]
@@ -143,12 +143,18 @@ class Validator(BaseValidator[Batch]):
         else:
             blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
             counts = [b.blocks.shape[0] for b in batches]
-        emb = self._model.encode_image(blocks, normalize=True, out_dtype=torch.float16).cpu()
-        out, i = [], 0
-        for b, k in zip(batches, counts):
-            out.append(dict(embeddings=emb[i:i + k].clone(), bboxes=b.bboxes.half()))
-            i += k
-        return out
+        host = self._to_host(self._model.encode_image(blocks, normalize=True, out_dtype=torch.float16))
+        bboxes = [b.bboxes.half() for b in batches]
+
+        def finish() -> list[dict]:
+            emb = host.get()
+            out, i = [], 0
+            for bb, k in zip(bboxes, counts):
+                out.append(dict(embeddings=emb[i:i + k].clone(), bboxes=bb))
+                i += k
+            return out
+
+        return finish if blocks.is_cuda else finish()
 
 
 if __name__ == '__main__':

@@ -38,7 +38,7 @@ class Validator(BaseValidator[Batch]):
     def _build_model(cls):
         return clip.load_default(True)
 
-    def _encode(self, batches: list[Batch]) -> list[torch.Tensor]:
+    def _encode(self, batches: list[Batch]):
         # reference _run_iter (globals.py:49-60): encode_image -> F.normalize -> squeeze -> .half(),
         # here for a whole batch of images with normalise + fp16 cast fused into the head kernel
         if batches[0].image.dtype == torch.uint8:
@@ -53,8 +53,14 @@ class Validator(BaseValidator[Batch]):
                                         out=images[i:i + 1])
         else:
             images = torch.stack([b.image for b in batches]).to(self._device, non_blocking=True)
-        emb = self._model.encode_image(images, normalize=True, out_dtype=torch.float16).cpu()
-        return [emb[i].clone() for i in range(len(batches))]
+        host = self._to_host(self._model.encode_image(images, normalize=True, out_dtype=torch.float16))
+        n = len(batches)
+
+        def finish() -> list[torch.Tensor]:
+            emb = host.get()
+            return [emb[i].clone() for i in range(n)]
+
+        return finish if images.is_cuda else finish()
 
 
 if __name__ == '__main__':

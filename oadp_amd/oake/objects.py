@@ -190,7 +190,7 @@ class Validator(BaseValidator[Batch]):
     def _n_crops(self, batch: Batch) -> int:
         return batch.bboxes.shape[0]
 
-    def _encode(self, batches: list[Batch]) -> list[dict]:
+    def _encode(self, batches: list[Batch]):
         # reference _run_iter (objects.py:316-338): mini-batches of `mini_batch_size` crops through
         # model.visual(objects, masks), normalise, cat, .half() x3
         if batches[0].crop_boxes is not None:
@@ -207,15 +207,21 @@ class Validator(BaseValidator[Batch]):
             sl = slice(i * self._mini_batch_size, (i + 1) * self._mini_batch_size)
             o = objects[sl].to(self._device, non_blocking=True)
             m = masks[sl].to(self._device, non_blocking=True)
-            embs.append(self._model.visual(o, m, normalize=True, out_dtype=torch.float16).cpu())
-        emb = torch.cat(embs) if embs else torch.zeros(0, 512, dtype=torch.float16)
-        out, i = [], 0
-        for b in batches:
-            n = b.bboxes.shape[0]
-            out.append(dict(embeddings=emb[i:i + n].clone(), bboxes=b.bboxes.half(),
-                            objectness=b.objectness.half()))
-            i += n
-        return out
+            embs.append(self._model.visual(o, m, normalize=True, out_dtype=torch.float16))
+        on_gpu = bool(embs) and embs[0].is_cuda
+        # one device -> host copy per flush, left in flight while the next flush is prepared (base._flush)
+        host = self._to_host(torch.cat(embs)) if embs else None
+        meta = [(b.bboxes.shape[0], b.bboxes.half(), b.objectness.half()) for b in batches]
+
+        def finish() -> list[dict]:
+            emb = host.get() if host is not None else torch.zeros(0, 512, dtype=torch.float16)
+            out, i = [], 0
+            for n, bboxes, objectness in meta:
+                out.append(dict(embeddings=emb[i:i + n].clone(), bboxes=bboxes, objectness=objectness))
+                i += n
+            return out
+
+        return finish if on_gpu else finish()
 
 
 if __name__ == '__main__':

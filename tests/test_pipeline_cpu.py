@@ -261,3 +261,42 @@ def test_objects_masks_vectorised_equals_per_proposal():
     got = ds._masks(fg, boxes)
     assert got.shape == want.shape == (n, 1, 14, 14) and got.dtype == want.dtype
     assert torch.equal(got, want)
+
+
+def test_one_flush_stays_in_flight(coco, tmp_path):
+    """_encode may return a closure (GPU: results still on the device): that flush is handed to the
+    writer when the NEXT one has been launched, the last one at the end — nothing is lost or reordered,
+    and a flush is never finished before it was launched."""
+    events = []
+
+    class Deferred(globals_.Validator):
+
+        def _encode(self, batches):
+            k = sum(1 for e, _ in events if e == 'launch')
+            events.append(('launch', k))
+            results = super()._encode(batches)          # CPU model: plain results
+            assert not callable(results)
+
+            def finish():
+                events.append(('finish', k))
+                return results
+            return finish
+
+    out = tmp_path / 'deferred'
+    v = Deferred('g', _synth.OracleModel(), dataloader=_dl(coco, out), batch_size=2, device='cpu')
+    c = v.run()
+    n_flush = (len(SIZES) + 1) // 2
+    assert c.images == len(SIZES)
+    assert sorted(p.name for p in out.iterdir()) == [f'{i:012d}.pth' for i in coco['ids']]
+    launches = [k for e, k in events if e == 'launch']
+    finishes = [k for e, k in events if e == 'finish']
+    assert launches == list(range(n_flush)) and finishes == list(range(n_flush))
+    for k in range(n_flush):   # finish(k) comes after launch(k + 1) while there is a next flush
+        later = ('launch', k + 1)
+        if later in events:
+            assert events.index(('finish', k)) > events.index(later)
+    # same payloads as the immediate path
+    ref = tmp_path / 'immediate'
+    globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, ref), batch_size=2, device='cpu').run()
+    for p in out.iterdir():
+        assert torch.equal(torch.load(p, 'cpu'), torch.load(ref / p.name, 'cpu'))
