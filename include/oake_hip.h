@@ -172,6 +172,13 @@ OAKE_API int oake_crop_resize_normalize(oake_handle* h, const uint8_t* d_image_h
                                const float* h_boxes_xyxy, int k, int out_size, int squash,
                                const float* h_mean3, const float* h_std3,
                                void* d_out, int out_dtype, void* stream);
+/* The same for the images of one flush in ONE call (a sweep otherwise pays an interpreter round trip
+ * per image): image i (d_images[i], heights[i] x widths[i]) contributes counts[i] boxes, taken in order
+ * from h_boxes_xyxy; d_out is [sum counts, 3, out, out], image after image. */
+OAKE_API int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, const uint8_t* const* d_images,
+                                     const int* heights, const int* widths, const float* h_boxes_xyxy,
+                                     const int* counts, int out_size, int squash, const float* h_mean3,
+                                     const float* h_std3, void* d_out, int out_dtype, void* stream);
 
 /* PIL Image.resize((dw, dh)) (default BICUBIC) of a uint8 HWC RGB device image — the pyramid step of
  * oadp/oake/blocks.py:72-76 — bit-exact with Pillow. */
@@ -207,6 +214,10 @@ OAKE_API int oake_encode_text(oake_handle* h, const int32_t* d_tokens, int n, in
  * oake_jpeg_info needs no handle and no GPU.
  */
 OAKE_API int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width, int* components);
+/* oake_jpeg_info for n files: heights[i] / widths[i] and status[i] (OAKE_OK, OAKE_ERR_UNSUPPORTED or
+ * OAKE_ERR_INVALID) per file; returns OAKE_OK unless an argument is NULL. */
+OAKE_API int oake_jpeg_info_batch(int n, const uint8_t* const* h_datas, const size_t* nbytes, int* heights,
+                         int* widths, int* status);
 OAKE_API int oake_decode_jpeg(oake_handle* h, const uint8_t* h_data, size_t nbytes, uint8_t* d_out_hwc,
                      size_t out_capacity, int* height, int* width, void* stream);
 /* A batch of files in one call: the Huffman passes run concurrently on `threads` host threads inside

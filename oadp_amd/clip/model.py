@@ -245,6 +245,41 @@ class VisionTransformer:
             _lib.check(self._lib, h, rc, 'oake_crop_resize_normalize')
         return out
 
+    def crop_resize_normalize_batch(self, images_u8: list[torch.Tensor], boxes: list, *, squash: bool = False,
+                                    out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """``torch.cat([crop_resize_normalize(im, b) for im, b in zip(images_u8, boxes)])`` in one native
+        call: ``boxes[i]`` ([k_i,4] floats) are the crops of ``images_u8[i]``."""
+        from .preprocess import CLIP_MEAN, CLIP_STD
+        if len(images_u8) != len(boxes):
+            raise ValueError('one box list per image')
+        n = self.input_resolution
+        if not images_u8:
+            return torch.empty((0, 3, n, n), dtype=out_dtype, device='cuda')
+        imgs, dev = [], None
+        for im in images_u8:
+            im, d = self._image_args(im)
+            if dev is not None and d != dev:
+                raise ValueError('all images must be on one device')
+            imgs.append(im)
+            dev = d
+        bs = [torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4) for b in boxes]
+        counts = [b.shape[0] for b in bs]
+        allb = torch.cat(bs).cpu().contiguous()
+        out = torch.empty((sum(counts), 3, n, n), dtype=out_dtype, device=imgs[0].device)
+        m = len(imgs)
+        ptrs = (C.c_void_p * m)(*[im.data_ptr() for im in imgs])
+        hs = (C.c_int * m)(*[im.shape[0] for im in imgs])
+        ws = (C.c_int * m)(*[im.shape[1] for im in imgs])
+        cs = (C.c_int * m)(*counts)
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            mean, std = (C.c_float * 3)(*CLIP_MEAN), (C.c_float * 3)(*CLIP_STD)
+            rc = self._lib.oake_crop_resize_normalize_batch(
+                h, m, ptrs, hs, ws, C.c_void_p(allb.data_ptr()), cs, n, int(squash), mean, std, out.data_ptr(),
+                _TORCH2OAKE[out_dtype], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_crop_resize_normalize_batch')
+        return out
+
     def resize_u8(self, image_u8: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
         """``PIL.Image.resize(size)`` (bicubic) of a uint8 HWC device image; ``size`` = (w, h)."""
         image_u8, dev = self._image_args(image_u8)
@@ -311,13 +346,14 @@ class VisionTransformer:
             else:
                 ptrs[i], lens[i] = C.cast(C.c_char_p(d), C.c_void_p), len(d)  # borrows d's buffer
         sizes, offsets, total = [], [], 0
-        hh, ww = C.c_int(0), C.c_int(0)
+        hs, ws, st = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+        self._lib.oake_jpeg_info_batch(n, ptrs, lens, hs, ws, st)
         for i in range(n):
-            ok = self._lib.oake_jpeg_info(ptrs[i], lens[i], C.byref(hh), C.byref(ww), None) == _lib.OAKE_OK
-            sizes.append((hh.value, ww.value) if ok else None)
+            ok = st[i] == _lib.OAKE_OK
+            sizes.append((hs[i], ws[i]) if ok else None)
             offsets.append(total)
             if ok:
-                total += (hh.value * ww.value * 3 + 255) & ~255
+                total += (hs[i] * ws[i] * 3 + 255) & ~255
         arena = torch.empty(max(total, 1), dtype=torch.uint8, device=torch.device('cuda', dev))
         outs = [arena[o:o + s[0] * s[1] * 3].view(s[0], s[1], 3) if s else None for s, o in zip(sizes, offsets)]
         base = arena.data_ptr()

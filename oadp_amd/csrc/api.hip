@@ -1072,6 +1072,30 @@ int oake_crop_resize_normalize(oake_handle* h, const uint8_t* d_image_hwc, int h
                       out_dtype);
 }
 
+int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, const uint8_t* const* d_images,
+                                     const int* heights, const int* widths, const float* h_boxes_xyxy,
+                                     const int* counts, int out_size, int squash, const float* h_mean3,
+                                     const float* h_std3, void* d_out, int out_dtype, void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (n_images < 0) return fail(h, OAKE_ERR_INVALID, "negative image count");
+  if (n_images == 0) return OAKE_OK;
+  if (!d_images || !heights || !widths || !h_boxes_xyxy || !counts || !d_out)
+    return fail(h, OAKE_ERR_INVALID, "null pointer");
+  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  const size_t crop_bytes = (size_t)3 * out_size * out_size * (out_dtype == OAKE_F32 ? 4 : 2);
+  size_t done = 0;
+  for (int i = 0; i < n_images; ++i) {
+    if (counts[i] < 0) return fail(h, OAKE_ERR_INVALID, "negative box count");
+    const int rc = oake_crop_resize_normalize(h, d_images[i], heights[i], widths[i], h_boxes_xyxy + 4 * done,
+                                              counts[i], out_size, squash, h_mean3, h_std3,
+                                              static_cast<char*>(d_out) + done * crop_bytes, out_dtype, stream);
+    if (rc != OAKE_OK) return rc;
+    done += (size_t)counts[i];
+  }
+  return OAKE_OK;
+}
+
 int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw, uint8_t* d_dst_hwc,
                    int dh, int dw, void* stream) {
   if (!h) return OAKE_ERR_INVALID;
@@ -1095,6 +1119,16 @@ int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width
   if (height) *height = f.height;
   if (width) *width = f.width;
   if (components) *components = f.ncomp;
+  return OAKE_OK;
+}
+
+int oake_jpeg_info_batch(int n, const uint8_t* const* h_datas, const size_t* nbytes, int* heights,
+                         int* widths, int* status) {
+  if (n < 0 || (n > 0 && (!h_datas || !nbytes || !heights || !widths || !status))) return OAKE_ERR_INVALID;
+  for (int i = 0; i < n; ++i) {
+    heights[i] = widths[i] = 0;
+    status[i] = oake_jpeg_info(h_datas[i], nbytes[i], &heights[i], &widths[i], nullptr);
+  }
   return OAKE_OK;
 }
 

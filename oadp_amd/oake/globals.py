@@ -44,13 +44,10 @@ class Validator(BaseValidator[Batch]):
         if batches[0].image.dtype == torch.uint8:
             # device preprocessing: one uint8 HWC upload per image, Pillow-exact resize on the GPU
             squash = getattr(self._dataloader.dataset.transform, 'squash', False)
-            v = self._model.visual
-            images = torch.empty((len(batches), 3, v.input_resolution, v.input_resolution),
-                                 dtype=torch.float16, device=self._device)
-            for i, image in enumerate(self._images_u8([b.image for b in batches])):
-                h, w = image.shape[:2]
-                v.crop_resize_normalize(image, [(0, 0, w, h)], squash=squash, out_dtype=torch.float16,
-                                        out=images[i:i + 1])
+            decoded = self._images_u8([b.image for b in batches])
+            images = self._model.visual.crop_resize_normalize_batch(
+                decoded, [[(0, 0, im.shape[1], im.shape[0])] for im in decoded], squash=squash,
+                out_dtype=torch.float16)
         else:
             images = torch.stack([b.image for b in batches]).to(self._device, non_blocking=True)
         host = self._to_host(self._model.encode_image(images, normalize=True, out_dtype=torch.float16))

@@ -212,6 +212,16 @@ def test_crops_into_preallocated_batch(cuda):
         want = v.crop_normalize(img, tiles, out_dtype=torch.float16)
         v.crop_normalize(img, tiles, out_dtype=torch.float16, out=batch[0:2])
         assert torch.equal(batch[0:2], want)
+    # several images in one native call == the per-image calls, image after image
+    img2 = torch.from_numpy(_synth(60, 75, 'grad', seed=6)).to(cuda)
+    boxes2 = [(0, 0, 75, 60)]
+    got = v.crop_resize_normalize_batch([img, img2, img], [boxes, boxes2, []], out_dtype=torch.float16)
+    want = torch.cat([v.crop_resize_normalize(img, boxes, out_dtype=torch.float16),
+                      v.crop_resize_normalize(img2, boxes2, out_dtype=torch.float16)])
+    assert torch.equal(got, want)
+    assert v.crop_resize_normalize_batch([], []).shape == (0, 3, n, n)
+    with pytest.raises(ValueError):
+        v.crop_resize_normalize_batch([img], [boxes, boxes2])
     with pytest.raises(ValueError):
         v.crop_resize_normalize(img, boxes, out_dtype=torch.float16, out=batch[0:2])
     with pytest.raises(ValueError):
