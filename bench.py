@@ -71,6 +71,8 @@ def main() -> None:
     from oadp_amd.weights import synthetic_state_dict
     if 'OAKE_GEMM_VARIANT' in os.environ:  # A/B runs of the GEMM tile configurations
         _lib.load().oake_debug_set_gemm_variant(int(os.environ['OAKE_GEMM_VARIANT']))
+    if 'OAKE_CLS_LAST' in os.environ:  # 0: run the last block for every token, as the reference does
+        _lib.load().oake_debug_set_cls_last(int(os.environ['OAKE_CLS_LAST']))
     if 'OAKE_ATTN_VARIANT' in os.environ:
         _lib.load().oake_debug_set_attention_variant(int(os.environ['OAKE_ATTN_VARIANT']))
     cdt = torch.float16 if args.dtype == 'f16' else torch.bfloat16

@@ -289,7 +289,7 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
  * of that kernel, 16 = sequences of at most 64 keys without a causal mask: the two waves of a (crop,
  * head) share its K / V in LDS, staged with LDS-DMA.  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
-/* GEMM configuration: -1 = automatic per shape, 0..4 = forced (see csrc/gemm.hip). */
+/* GEMM configuration: -1 = automatic per shape, 0..6 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
 /* x[m,n] (16-bit, in place) += A * W^T + bias — the residual epilogue of out_proj / c_proj.  On the
  * persistent kernel (large m) d_rowpart [m, 16, 2] fp32 (or NULL) receives (sum, sum of squares) of
@@ -299,6 +299,10 @@ OAKE_API int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const flo
 /* GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside), n < 0 = M slabs of
  * -n tiles (column-major inside). */
 OAKE_API int oake_debug_set_gemm_panel(int panel);
+/* oake_encode_image computes the last block for the CLS rows only (the only rows ln_post reads): K / V
+ * projections of all tokens, everything else of that block for one row per image.  0 = run the block for
+ * every token as the reference does (A/B runs, tests).  Default 1. */
+OAKE_API int oake_debug_set_cls_last(int enable);
 /* Debug: device buffer of 4608 uint64 receiving per-tile cycle stamps of the production GEMM
  * (entry, tile start, epilogue start, epilogue end; then per-block wall-clock entry/exit), or NULL. */
 OAKE_API int oake_debug_set_gemm_trace(void* d_trace);

@@ -69,6 +69,7 @@ SIGNATURES = {
     'oake_debug_set_gemm_variant': (_I, [_I]),
     'oake_debug_gemm_resid16': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_set_gemm_panel': (_I, [_I]),
+    'oake_debug_set_cls_last': (_I, [_I]),
     'oake_debug_set_gemm_trace': (_I, [_VP]),
 }
 

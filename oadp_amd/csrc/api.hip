@@ -39,6 +39,9 @@ extern unsigned long long* g_gemm_trace;
 using namespace oake;
 
 namespace {
+// encode_image: run the last block for the CLS rows only (debug switch: 0 = all rows, as the reference)
+int g_cls_last = 1;
+
 
 thread_local std::string g_create_error;
 
@@ -99,6 +102,7 @@ struct oake_handle {
   float* y = nullptr;
   float* rowstat = nullptr;   // [B*L, 2] LayerNorm (rstd, -mean*rstd) of the residual rows
   float* rowpart = nullptr;   // [B*L, 16, 2] (sum, sum^2) slices handed from GEMM to GEMM
+  void* zero_mask = nullptr;  // [B, L-1] 16-bit zeros: the CLS rows of the last block mask nothing
   bool stat_fused = false;    // this pass: statistics via rowpart (else the rowstat kernel)
   int nparts = 0;             // valid slices per row in rowpart (1 after embed, width/64 after a GEMM)
   float* e32 = nullptr;       // [B, embed] fp32 head projection
@@ -306,7 +310,7 @@ void oake_destroy(oake_handle* h) {
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
                   h->yn, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
-                  h->rowstat, h->rowpart, h->jp_coefs, h->jp_planes, h->tok_emb};
+                  h->rowstat, h->rowpart, h->zero_mask, h->jp_coefs, h->jp_planes, h->tok_emb};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& l : h->layers) {
@@ -442,6 +446,8 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
   A((void**)&h->y, B * C * 4);
   A((void**)&h->rowstat, (R + 2) * 2 * 4);
   A((void**)&h->rowpart, R * 32 * 4);
+  A(&h->zero_mask, B * (L > 1 ? L - 1 : 1) * 2);  // "nothing masked" for the CLS rows of the last block
+  if (rc == OAKE_OK && hipMemset(h->zero_mask, 0, B * (L > 1 ? L - 1 : 1) * 2) != hipSuccess) rc = OAKE_ERR_HIP;
   A((void**)&h->e32, B * E * 4);
   A(&h->yn, B * C * e16());
   if (rc != OAKE_OK) {
@@ -866,12 +872,44 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
     const char* imgs = reinterpret_cast<const char*>(d_images) + (size_t)b0 * img_bytes;
     char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
     if ((rc = patch_embed(h, s, imgs, in_dtype, nb))) return rc;
+    // Only the CLS row of the last block reaches ln_post (VisionTransformer.forward: x[:, 0, :]), so of
+    // that block only its K / V projections are needed for all tokens; the query, the attention
+    // output, out_proj and the MLP are computed for the CLS rows alone — the same dead-row elimination
+    // as the objects stream's, through the same code: the CLS rows are copied
+    // to rows T .. T+nb and attend over the patch rows + themselves (object_attention with a zero mask).
+    // Identical results row for row; 6.7 % fewer FLOPs per image at 12 layers.
+    const bool cls_last = g_cls_last && L >= 2 && L <= 1024;
+    const size_t xs = h->xdt == DT_F32 ? 4 : 2;
+    char* yrows = reinterpret_cast<char*>(h->x) + (size_t)T * C * xs;
     for (int l = 0; l < c.layers; ++l) {
       const LayerW& w = h->layers[l];
-      if ((rc = main_in_proj(h, s, w, T, false))) return rc;
-      if ((rc = main_block_tail(h, s, w, nb))) return rc;
+      if (l + 1 < c.layers || !cls_last) {
+        if ((rc = main_in_proj(h, s, w, T, false))) return rc;
+        if ((rc = main_block_tail(h, s, w, nb))) return rc;
+        continue;
+      }
+      RUN(h, s, "copy_cls", 0.0, 2.0 * nb * C * xs,
+          hipMemcpy2DAsync(yrows, (size_t)C * xs, h->x, (size_t)L * C * xs, (size_t)C * xs, nb,
+                           hipMemcpyDeviceToDevice, s));
+      if ((rc = in_proj_rows(h, s, w, 0, T, true, "gemm_kv"))) return rc;
+      const bool fused = h->stat_fused;
+      h->stat_fused = false;  // (the small kernels take (rstd, -mean rstd) from a rowstat pass)
+      rc = in_proj_rows(h, s, w, T, nb, false, "gemm_qkv_cls");
+      if (rc == OAKE_OK) {
+        const char* qkv_y = reinterpret_cast<const char*>(h->qkv) + (size_t)T * 3 * C * 2;
+        char* att_y = reinterpret_cast<char*>(h->att) + (size_t)T * C * 2;
+        RUNK(h, s, "cls_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
+             launch_object_attention(h->dt16, h->qkv, qkv_y, h->zero_mask, DT_F16, att_y, nb, L, c.heads, s));
+        rc = mlp_rows(h, s, w, T, nb, "_cls");
+      }
+      h->stat_fused = fused;
+      if (rc) return rc;
     }
-    if ((rc = head(h, s, h->x, h->xdt, (long)L * C, outp, out_dtype, normalize, nb))) return rc;
+    if (cls_last) {
+      if ((rc = head(h, s, yrows, h->xdt, (long)C, outp, out_dtype, normalize, nb))) return rc;
+    } else {
+      if ((rc = head(h, s, h->x, h->xdt, (long)L * C, outp, out_dtype, normalize, nb))) return rc;
+    }
   }
   return OAKE_OK;
 }
@@ -1394,6 +1432,11 @@ int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const float* d_bia
   a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_x; a.M = m; a.N = n; a.K = k; a.ldo = n;
   a.rowpart_out = gemm_uses_persistent(m, n, k) ? d_rowpart : nullptr;
   return dbg(launch_gemm(dtype16, EPI_RESID16, a, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_set_cls_last(int enable) {
+  g_cls_last = enable ? 1 : 0;
+  return OAKE_OK;
 }
 
 int oake_debug_set_gemm_panel(int panel) {

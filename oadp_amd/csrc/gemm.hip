@@ -544,6 +544,106 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small-problem kernel: gemm_kernel with a 4-slot ring and counted waits.  With a few hundred rows
+// (the CLS rows of the last block, the object-token stream, the head projection) a launch is a
+// handful of 64x64 tiles per CU and its time is nk x (DMA latency): gemm_kernel's barrier retires the
+// NEXT K-tile's DMA every iteration (vmcnt(0)), so one L2 round trip is exposed per K-tile.  Here
+// three K-tiles are in flight and an iteration waits only for the oldest (s_waitcnt vmcnt(2 x pieces)),
+// raw s_barrier instead of __syncthreads (whose fence would wait for everything).
+template <typename T, int EPI, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_deep_kernel(const T* __restrict__ A,
+                                                                const T* __restrict__ W, int M, int N,
+                                                                int K, EpiParams ep, TileMap tmap) {
+  typedef typename T16<T>::vec8 vec8;
+  constexpr bool PAIRED = EpiTraits<EPI>::kPaired;
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int kATileBytes = BM * kRowBytes;
+  constexpr int kStageBytes = (BM + BN) * kRowBytes;
+  constexpr int NINST = (BM + BN) / 8;  // 1-KiB DMA pieces per stage
+  static_assert(NINST % NW == 0, "every wave issues the same number of pieces (counted vmcnt)");
+  constexpr int NSLOT = NINST / NW;
+  constexpr int NSTAGE = 4;
+  static_assert(2 * NSLOT <= 63, "vmcnt immediate");
+  static_assert(TM % 16 == 0 && TN % 32 == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  int m0, n0;
+  tile_origin(tmap, xcd_remap(blockIdx.x, tmap.nwg), BM, BN, m0, n0);
+
+  const char* src[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j)
+    src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, wid + NW * j, lane);
+#define OAKE_DEEP_STAGE(kt_)                                                                   \
+  do {                                                                                         \
+    char* _base = smem + ((kt_) % NSTAGE) * kStageBytes;                                       \
+    const size_t _koff = (size_t)(kt_) * (BK * 2);                                             \
+    _Pragma("unroll") for (int _j = 0; _j < NSLOT; ++_j)                                       \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                         \
+                                         (lds_ptr_t)(_base + (wid + NW * _j) * 1024), 16, 0, 0); \
+  } while (0)
+  // vmcnt immediate: bits [3:0] | [15:14]; expcnt 7 = "don't wait"; lgkmcnt 0 (own LDS reads done)
+#define OAKE_DEEP_WAIT(n_) __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14))
+
+  const int frow = lane & 15;
+  const int fg = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  const int a_base = (wm * TM + frow) * kRowBytes;
+  const int b_base = kATileBytes + (wn * TN + frow) * kRowBytes;
+  const int koff0 = ((0 * 4 + fg) ^ fsw) << 4;
+  const int koff1 = ((1 * 4 + fg) ^ fsw) << 4;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  OAKE_DEEP_STAGE(0);
+  if (nk > 1) OAKE_DEEP_STAGE(1);
+  if (nk > 2) OAKE_DEEP_STAGE(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // K-tile kt has landed when at most the pieces of the (up to two) younger K-tiles are in flight
+    const int younger = nk - 1 - kt;
+    if (younger >= 2) OAKE_DEEP_WAIT(2 * NSLOT);
+    else if (younger == 1) OAKE_DEEP_WAIT(NSLOT);
+    else OAKE_DEEP_WAIT(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // ... in every wave; and everybody is done with K-tile kt - 1's slot
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 3 < nk) OAKE_DEEP_STAGE(kt + 3);
+    const char* st = smem + (kt % NSTAGE) * kStageBytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int koff = kk == 0 ? koff0 : koff1;
+      vec8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const vec8*>(st + a_base + i * 16 * kRowBytes + koff);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        bf[i] = *reinterpret_cast<const vec8*>(st + b_base + i * 16 * kRowBytes + koff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+    }
+  }
+#undef OAKE_DEEP_STAGE
+#undef OAKE_DEEP_WAIT
+  tile_epilogue<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, false,
+                                m0 + BM <= M && n0 + BN <= N);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Production kernel: persistent, ping-pong compute waves + dedicated DMA waves.
 //
 // What the cycle traces of the simple kernel showed (s_memtime stamps per K-tile, 160x256 tile):
@@ -961,6 +1061,27 @@ hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
 }
 
 template <typename T, int EPI, int BM, int BN, int WM, int WN>
+hipError_t launch_deep(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 4 * (BM + BN) * kRowBytes;
+  static bool attr_set = false;
+  auto kern = gemm_deep_kernel<T, EPI, BM, BN, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const TileMap tmap = make_tilemap(a, BM, BN);
+  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum,
+               reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
+               a.nparts, 1.0f / (float)a.K};
+  OAKE_LAUNCH(kern, dim3(tmap.nwg), dim3(WM * WN * 64), lds, s, reinterpret_cast<const T*>(a.A),
+              reinterpret_cast<const T*>(a.W), a.M, a.N, a.K, ep, tmap);
+  return hipGetLastError();
+}
+
+template <typename T, int EPI, int BM, int BN, int WM, int WN>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
   static_assert(BM <= 160 && BN <= 256, "EpiLds layout");
@@ -998,7 +1119,8 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
 // Configurations.  0: simple 128x128 (4 waves)   1: simple 160x256 (8 waves 2x4)
 //                  2: simple 320x128 (8 waves 4x2)   3: simple 256x256 (8 waves 2x4)
 //                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production]
-//                  5: simple 64x64 (4 waves) for the few-hundred-row problems (head, object stream)
+//                  5: deep-ring 64x64 (4 waves, 4-slot ring) for the few-hundred-row problems (head,
+//                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
 template <typename T, int EPI>
 hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
   switch (variant) {
@@ -1007,15 +1129,17 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 2: return launch_simple<T, EPI, 320, 128, 4, 2>(a, s);
     case 3: return launch_simple<T, EPI, 256, 256, 2, 4>(a, s);
     case 4: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
-    case 5: return launch_simple<T, EPI, 64, 64, 2, 2>(a, s);
+    case 5: return launch_deep<T, EPI, 64, 64, 2, 2>(a, s);
+    case 6: return launch_simple<T, EPI, 64, 64, 2, 2>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 int pick_variant(const GemmArgs& a) {
   if (g_gemm_variant >= 0) return g_gemm_variant;
-  if ((long)a.M * a.N <= 512 * 1024) return 5;  // spread small problems over more CUs
-  if (a.M <= 1024 || a.N < 256) return 0;
+  // few-hundred-row problems: 64x64 tiles spread over the CUs, deep ring against the per-K-tile latency
+  if ((long)a.M * a.N <= 512 * 1024 || a.M <= 1024) return 5;
+  if (a.N < 256) return 0;
   return 4;
 }
 

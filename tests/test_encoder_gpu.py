@@ -190,3 +190,29 @@ def test_errors_are_loud(cuda):
     with pytest.raises(ValueError):
         model.visual(torch.zeros(1, 3, 224, 224, device=cuda), torch.zeros(1, 1, 14, 14, device=cuda))
     assert model.encode_image(torch.zeros(0, 3, 224, 224, device=cuda)).shape == (0, 64)
+
+
+@pytest.mark.parametrize('resid32', [False, True])
+@pytest.mark.parametrize('cfg,n', [(TINY, 7), (None, 48), (dict(TINY, layers=1), 3)])
+def test_last_block_for_cls_rows_only_is_exact_elimination(cuda, cfg, n, resid32):
+    """encode_image runs the last block's query / attention output / out_proj / MLP for the CLS rows only
+    (ln_post reads nothing else).  Against the all-rows execution the reference performs: the same
+    embeddings up to the rounding of different tile shapes, and both within tolerance of the oracle."""
+    from oadp_amd import _lib
+    lib = _lib.load()
+    sd = synthetic_state_dict(**cfg) if cfg else synthetic_state_dict()
+    model, _ = clip.load(sd, max_batch=64, residual_dtype=torch.float32 if resid32 else None)
+    x = synthetic_images(n, seed=3).to(cuda)
+    try:
+        lib.oake_debug_set_cls_last(0)
+        full = model.encode_image(x, normalize=True, out_dtype=torch.float32)
+    finally:
+        lib.oake_debug_set_cls_last(1)
+    cls = model.encode_image(x, normalize=True, out_dtype=torch.float32)
+    cos = torch.nn.functional.cosine_similarity(full, cls, dim=1)
+    print(f'max|cls - full|={(full - cls).abs().max().item():.3e} min cos={cos.min().item():.7f}')
+    assert cos.min().item() > 0.99999
+    torch.testing.assert_close(cls, full, rtol=1e-3, atol=6e-4)
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(**cfg) if cfg else ViTConfig(), x.cpu()))
+    _check(cls, ref, 1e-3, 1e-3)
+    _check(full, ref, 1e-3, 1e-3)
