@@ -171,7 +171,10 @@ def main() -> None:
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'oadp.oake.globals: ViT-B/32 encode_image + L2-normalise + fp16, '
                                    f'single 224^2 crop per image, batch {args.batch} per GPU, '
-                                   'random-init weights, device-resident N(0,1) inputs',
+                                   'random-init weights, device-resident N(0,1) inputs'
+                                   + ('' if os.environ.get('OAKE_CLS_LAST') == '0' else
+                                      '; last block evaluated for the CLS rows only (the rows ln_post reads: '
+                                      'identical embeddings, 6.6 % fewer FLOPs; OAKE_CLS_LAST=0 runs every row)'),
                        'batch_per_gpu': args.batch, 'sharding': f'images x{world} (no data-path collective)'},
             'mfma_roofline_frac_e2e': round(value / world * flop_image / PEAK_MFMA_DENSE, 4),
             'flop_per_image': {'model': FLOP_PER_IMAGE, 'executed': flop_image},
