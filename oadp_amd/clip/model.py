@@ -79,8 +79,16 @@ class VisionTransformer:
         self.max_batch = max_batch
         self.device = device
         self._lib = _lib.load()
-        self._handle = None
-        self._handle_key = None
+        # Lanes: independent native handles (weights, activations and scratch each) so that consecutive
+        # batches can run on different HIP streams and fill each other's kernel start-up and tail
+        # (+10 % at batch 256, tools/two_stream_bench.py).  `lane` selects the handle every call on this
+        # object uses; the caller pairs a lane with a stream (BaseValidator._flush, bench.py).
+        self.lane = 0
+        self._lanes: dict[int, tuple] = {}
+
+    @property
+    def _handle(self):
+        return self._lanes.get(self.lane, (None, None))[0]
 
     # -- reference surface -----------------------------------------------------------------
     def interpolate_positional_embedding(self, size: tuple[int, int]) -> torch.Tensor:
@@ -118,9 +126,12 @@ class VisionTransformer:
         pos = pos.data if isinstance(pos, torch.nn.Parameter) else pos
         key = (device_index, stride, pad, pos.data_ptr(), tuple(pos.shape), self.compute_dtype,
                self.residual_dtype, self.max_batch)
-        if self._handle is not None and key == self._handle_key:
-            return self._handle
-        self.close()
+        cur = self._lanes.get(self.lane)
+        if cur is not None and key == cur[1]:
+            return cur[0]
+        if cur is not None:  # geometry / dtype changed (objects-mode surgery): rebuild this lane
+            self._lib.oake_destroy(cur[0])
+            del self._lanes[self.lane]
         lib = self._lib
         cfg = _lib.OakeConfig()
         lib.oake_default_config(C.byref(cfg))
@@ -148,14 +159,13 @@ class VisionTransformer:
         except Exception:
             lib.oake_destroy(h)
             raise
-        self._handle, self._handle_key = h, key
+        self._lanes[self.lane] = (h, key)
         return h
 
     def close(self) -> None:
-        if self._handle is not None:
-            self._lib.oake_destroy(self._handle)
-            self._handle = None
-            self._handle_key = None
+        for h, _ in self._lanes.values():
+            self._lib.oake_destroy(h)
+        self._lanes.clear()
 
     def __del__(self) -> None:  # pragma: no cover
         try:

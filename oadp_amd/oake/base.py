@@ -278,7 +278,7 @@ class BaseValidator(ABC, Generic[T]):
     def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
                  batch_size: int = 256, device: torch.device | str | None = None,
                  writer_threads: int = 4, decode_threads: int = 16, prefetch: int = 512,
-                 **kwargs) -> None:
+                 streams: int = 2, **kwargs) -> None:
         self.name = name
         self._model = model
         self._log_interval = (log or {}).get('interval', 50)
@@ -294,6 +294,12 @@ class BaseValidator(ABC, Generic[T]):
         self._inflight: tuple[list, Any] | None = None   # the flush whose results are still on the GPU
         self._host_bufs: list[torch.Tensor | None] = [None, None]
         self._host_slot = 0
+        # consecutive flushes alternate over `streams` lanes = (native handle, HIP stream) pairs: the
+        # kernels of two independent batches fill each other's start-up and tail (GPU only)
+        self._n_lanes = max(1, int(streams)) if self._device.type == 'cuda' and hasattr(
+            getattr(model, 'visual', None), 'lane') else 1
+        self._lane_streams: list | None = None
+        self._flush_no = 0
         self._dataloader = self._build_dataloader(Config(dataloader))
 
     # -- reference surface ----------------------------------------------------------------------
@@ -373,7 +379,20 @@ class BaseValidator(ABC, Generic[T]):
         one has been launched (one flush of look-ahead; file order is unchanged)."""
         if not pending:
             return
-        results = self._encode(pending)
+        if self._n_lanes > 1:
+            if self._lane_streams is None:
+                self._lane_streams = [torch.cuda.Stream(self._device) for _ in range(self._n_lanes)]
+            lane = self._flush_no % self._n_lanes
+            self._flush_no += 1
+            visual = self._model.visual
+            visual.lane = lane
+            try:
+                with torch.cuda.stream(self._lane_streams[lane]):
+                    results = self._encode(pending)
+            finally:
+                visual.lane = 0
+        else:
+            results = self._encode(pending)
         if callable(results):
             previous, self._inflight = self._inflight, (list(pending), results)
             if previous is not None:

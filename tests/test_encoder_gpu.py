@@ -216,3 +216,26 @@ def test_last_block_for_cls_rows_only_is_exact_elimination(cuda, cfg, n, resid32
     ref = l2_normalize(encode_image_ref(sd, ViTConfig(**cfg) if cfg else ViTConfig(), x.cpu()))
     _check(cls, ref, 1e-3, 1e-3)
     _check(full, ref, 1e-3, 1e-3)
+
+
+def test_lanes_are_independent_handles_on_their_own_streams(cuda):
+    """visual.lane selects one of several native handles; consecutive batches on different lanes and HIP
+    streams (what the sweep and bench.py do) give the results of the single-stream execution."""
+    sd = synthetic_state_dict(**TINY)
+    model, _ = clip.load(sd, max_batch=16)
+    xs = [synthetic_images(5, seed=s).to(cuda) for s in range(4)]
+    want = [model.encode_image(x, normalize=True, out_dtype=torch.float32).clone() for x in xs]
+    streams = [torch.cuda.Stream(cuda) for _ in range(2)]
+    torch.cuda.synchronize()
+    got = []
+    for i, x in enumerate(xs):
+        model.visual.lane = i % 2
+        with torch.cuda.stream(streams[i % 2]):
+            got.append(model.encode_image(x, normalize=True, out_dtype=torch.float32))
+    model.visual.lane = 0
+    torch.cuda.synchronize()
+    assert len(model.visual._lanes) == 2 and len({h.value for h, _ in model.visual._lanes.values()}) == 2
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    model.visual.close()
+    assert not model.visual._lanes

@@ -1,4 +1,6 @@
-"""Experiment: two half-batches on two streams (two handles) vs one full batch — GPU box only."""
+"""Experiment: batches of 256 crops alternating over 1, 2 or 3 handles / HIP streams (the kernels of
+independent batches fill each other's start-up and tail) vs one stream — GPU box only.
+Also the older question: one batch split in halves over two streams."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,24 +12,25 @@ sd = synthetic_state_dict()
 B = 256
 x = torch.randn(B, 3, 224, 224, device=dev)
 
-def run(nsplit, steps=30):
-    hb = B // nsplit
-    models = [clip.load(sd, max_batch=hb)[0] for _ in range(nsplit)]
-    streams = [torch.cuda.Stream() for _ in range(nsplit)]
-    xs = [x[i * hb:(i + 1) * hb].contiguous() for i in range(nsplit)]
-    def step():
-        for m, s, xi in zip(models, streams, xs):
-            with torch.cuda.stream(s):
-                m.encode_image(xi, normalize=True, out_dtype=torch.float16)
-    for _ in range(5):
-        step()
+
+def run(nstream, batch, steps=60):
+    models = [clip.load(sd, max_batch=batch)[0] for _ in range(nstream)]
+    streams = [torch.cuda.Stream() for _ in range(nstream)]
+    xs = x[:batch].contiguous()
+    def step(i):
+        with torch.cuda.stream(streams[i % nstream]):
+            models[i % nstream].encode_image(xs, normalize=True, out_dtype=torch.float16)
+    for i in range(3 * nstream):
+        step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        step(i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(f'{nsplit} stream(s) x {hb} crops: {dt*1e3:.3f} ms/step  {B/dt:.0f} img/s', flush=True)
+    print(f'{nstream} stream(s), batches of {batch}: {dt*1e3:.3f} ms per batch  {batch/dt:.0f} img/s', flush=True)
+    del models
 
-for n in (1, 2, 4, 1, 2):
-    run(n)
+
+for n, b in ((1, 256), (2, 256), (3, 256), (1, 256), (2, 256), (2, 128)):
+    run(n, b)
