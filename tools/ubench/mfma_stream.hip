@@ -2,10 +2,12 @@
 // accumulator tiles, 160 registers) straight through a K-tile — 80 v_mfma_f32_16x16x32_f16 with the
 // fragment reads (ds_read_b128 from a swizzled 128-B-row LDS tile, as gemm.hip) software-pipelined under
 // them — against the production layout's measured 1586 cycles per K-tile (two waves per SIMD in
-// alternating load / MFMA phases).  No DMA, no barriers.  RESULT: hipcc keeps the 160 accumulator registers
-// in AGPRs and moves them around every iteration, so these variants measure 26-31 cycles per MFMA of
-// compiler-made traffic; bare_kernel below (5 x 4 tiles, in place) gives the hardware's 17.2.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_stream tools/ubench/mfma_stream.hip && /tmp/mfma_stream
+// alternating load / MFMA phases).  No DMA, no barriers.  RESULTS: by default hipcc keeps the 160
+// accumulator registers in AGPRs and moves them around every iteration (26-31 cycles per MFMA of
+// compiler-made traffic); built with -mllvm -amdgpu-mfma-vgpr-form=1: MFMAs only 16.3 cycles per MFMA,
+// unpipelined reads 23.2, reads pipelined over the kk halves 17.7 (1416 cycles per K-tile).
+// bare_kernel (5 x 4 tiles, in place either way): 17.2.
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 -o /tmp/mfma_stream tools/ubench/mfma_stream.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
