@@ -289,7 +289,7 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
  * of that kernel, 16 = sequences of at most 64 keys without a causal mask: the two waves of a (crop,
  * head) share its K / V in LDS, staged with LDS-DMA.  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
-/* GEMM configuration: -1 = automatic per shape, 0..6 = forced (see csrc/gemm.hip). */
+/* GEMM configuration: -1 = automatic per shape, 0..7 = forced (see csrc/gemm.hip). */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
 /* x[m,n] (16-bit, in place) += A * W^T + bias — the residual epilogue of out_proj / c_proj.  On the
  * persistent kernel (large m) d_rowpart [m, 16, 2] fp32 (or NULL) receives (sum, sum of squares) of

@@ -644,6 +644,144 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_deep_kernel(const T* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// One-tile-per-block kernel with ONE compute wave per SIMD (experiment; variant 7):
+// 4 compute waves of BM x 64 (10 x 4 accumulator tiles = 160 registers, 2 waves per SIMD = 256 each)
+// + 4 DMA waves.  A compute wave streams its 80 MFMAs per K-tile with the fragment reads
+// software-pipelined under them (tools/ubench/mfma_stream.hip: 17.7 cycles per MFMA against the 19.8 of
+// the alternating-phase layout), two barriers per K-tile.  Ring of 3 stages: barrier g (start of K-tile
+// g) frees K-tile g - 1's stage for the DMA of g + 2; barrier g' (80 % through K-tile g) publishes K-tile
+// g + 1, whose first fragments the stream prefetches under the last MFMAs of g — so a K-tile has 1.8
+// K-tiles of time to land.
+template <typename T, int EPI, int BM, int BN>
+__global__ __launch_bounds__(512) void gemm_q4_kernel(const T* __restrict__ A, const T* __restrict__ W, int M,
+                                                      int N, int K, EpiParams ep, TileMap tmap) {
+  typedef typename T16<T>::vec8 vec8;
+  constexpr bool PAIRED = EpiTraits<EPI>::kPaired;
+  static_assert(BN == 256 && BM % 16 == 0, "four compute waves of BM x 64");
+  constexpr int MI = BM / 16, NI = 4, TN = 64;
+  constexpr int kATileBytes = BM * kRowBytes;
+  constexpr int kStageBytes = (BM + BN) * kRowBytes;
+  constexpr int NINST = (BM + BN) / 8;
+  static_assert(NINST % 4 == 0, "pieces split evenly over the DMA waves");
+  constexpr int NPL = NINST / 4;
+  constexpr int NSTAGE = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int m0, n0;
+  tile_origin(tmap, xcd_remap(blockIdx.x, tmap.nwg), BM, BN, m0, n0);
+  const int nk = K / BK;
+  char* elds = smem + NSTAGE * kStageBytes;
+#define OAKE_Q4_BAR()                  \
+  do {                                 \
+    __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_barrier();      \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
+
+  if (wid >= 4) {
+    // ================= DMA wave =================
+    const int lw = wid - 4;
+    const char* src[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + 4 * j, lane);
+#define OAKE_Q4_STAGE(kt_)                                                                       \
+  do {                                                                                           \
+    char* _base = smem + ((kt_) % NSTAGE) * kStageBytes;                                         \
+    const size_t _koff = (size_t)(kt_) * (BK * 2);                                               \
+    _Pragma("unroll") for (int _j = 0; _j < NPL; ++_j)                                           \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                           \
+                                         (lds_ptr_t)(_base + (lw + 4 * _j) * 1024), 16, 0, 0);   \
+  } while (0)
+    if (lw == 0 && ep.bias != nullptr && EPI != EPI_PATCH && EPI != EPI_PATCH16) {
+      int n = n0 + 4 * lane;
+      n = n + 4 <= N ? n : N - 4;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.bias + n), (lds_ptr_t)(elds + EpiLds::kBias), 16, 0, 0);
+    }
+    // vmcnt immediate: bits [3:0] | [15:14]; expcnt 7 and lgkmcnt 15 = "don't wait"
+#define OAKE_Q4_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
+    OAKE_Q4_STAGE(0);
+    if (nk > 1) OAKE_Q4_STAGE(1);
+    if (nk > 1) OAKE_Q4_VMCNT(NPL); else OAKE_Q4_VMCNT(0);  // K-tile 0 has landed
+    for (int g = 0; g < nk; ++g) {
+      OAKE_Q4_BAR();  // barrier g (start of K-tile g): K-tile g is readable, K-tile g - 1's stage is free
+      if (g + 2 < nk) {
+        OAKE_Q4_STAGE(g + 2);
+        OAKE_Q4_VMCNT(NPL);  // K-tile g + 1 (issued a K-tile ago) has landed; g + 2 stays in flight
+      } else {
+        OAKE_Q4_VMCNT(0);
+      }
+      OAKE_Q4_BAR();  // barrier g' (80 % through K-tile g): K-tile g + 1 is readable
+    }
+#undef OAKE_Q4_VMCNT
+#undef OAKE_Q4_STAGE
+    return;
+  }
+
+  // ================= compute wave =================
+  const int wn = wid;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int fsw = (fr >> 1) & 7;
+  const int a_off = fr * kRowBytes, b_off = kATileBytes + (wn * TN + fr) * kRowBytes;
+  const int kx0 = ((0 * 4 + fg) ^ fsw) << 4, kx1 = ((1 * 4 + fg) ^ fsw) << 4;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  vec8 bf[2][NI];
+  vec8 af[5];
+  OAKE_Q4_BAR();  // barrier 0
+  {
+    const char* st = smem;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf[0][j] = *reinterpret_cast<const vec8*>(st + b_off + j * 16 * kRowBytes + kx0);
+    af[0] = *reinterpret_cast<const vec8*>(st + a_off + kx0);
+    af[1] = *reinterpret_cast<const vec8*>(st + a_off + 16 * kRowBytes + kx0);
+  }
+  int stage = 0;
+  for (int g = 0; g < nk; ++g) {
+    if (g > 0) OAKE_Q4_BAR();  // barrier g (the fragments prefetched for this K-tile are already in flight)
+    const char* st = smem + stage * kStageBytes;
+    const int nstage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    const char* sn = smem + nstage * kStageBytes;  // K-tile g + 1 (landed by barrier g), if any
+    const bool more = g + 1 < nk;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int kx = hh == 0 ? kx0 : kx1, kxn = hh == 0 ? kx1 : kx0;
+      const char* a0 = st + a_off + kx;
+      // the next half: the other kk of this K-tile, or kk = 0 of K-tile g + 1
+      const char* an = (hh == 0 ? st : sn) + a_off + kxn;
+      const char* bn = (hh == 0 ? st : sn) + b_off + kxn;
+      const bool pre = hh == 0 || more;
+      // B fragments of the next half: early in half 0 (same K-tile), late in half 1 (next K-tile: it is
+      // readable only behind barrier g', placed before row block MI - NI of half 1)
+      const int b_first = hh == 0 ? 2 : MI - NI;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        if (hh == 1 && mi == b_first) OAKE_Q4_BAR();  // barrier g'
+        const int cur = mi % 5, nxt = (mi + 2) % 5;
+        if (mi + 2 < MI)
+          af[nxt] = *reinterpret_cast<const vec8*>(a0 + (mi + 2) * 16 * kRowBytes);
+        else if (pre)
+          af[nxt] = *reinterpret_cast<const vec8*>(an + (mi + 2 - MI) * 16 * kRowBytes);
+        if (mi >= b_first && mi < b_first + NI && pre)
+          bf[hh ^ 1][mi - b_first] = *reinterpret_cast<const vec8*>(bn + (mi - b_first) * 16 * kRowBytes);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[mi][j] = T16<T>::mfma(bf[hh][j], af[cur], acc[mi][j]);
+        if (mi >= b_first && mi < b_first + NI) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+    }
+    stage = nstage;
+  }
+#undef OAKE_Q4_BAR
+  tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + fr, n0 + wn * TN, fg, M, N, ep, false,
+                                    m0 + BM <= M && n0 + BN <= N, elds, wn * TN, fr);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Production kernel: persistent, ping-pong compute waves + dedicated DMA waves.
 //
 // What the cycle traces of the simple kernel showed (s_memtime stamps per K-tile, 160x256 tile):
@@ -1081,6 +1219,28 @@ hipError_t launch_deep(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <typename T, int EPI, int BM, int BN>
+hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
+  static bool attr_set = false;
+  auto kern = gemm_q4_kernel<T, EPI, BM, BN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (a.K < 2 * BK) return launch_simple<T, EPI, 128, 128, 2, 2>(a, s);
+  const TileMap tmap = make_tilemap(a, BM, BN);
+  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum,
+               reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
+               a.nparts, 1.0f / (float)a.K};
+  OAKE_LAUNCH(kern, dim3(tmap.nwg), dim3(512), lds, s, reinterpret_cast<const T*>(a.A),
+              reinterpret_cast<const T*>(a.W), a.M, a.N, a.K, ep, tmap);
+  return hipGetLastError();
+}
+
 template <typename T, int EPI, int BM, int BN, int WM, int WN>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
@@ -1121,6 +1281,7 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
 //                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production]
 //                  5: deep-ring 64x64 (4 waves, 4-slot ring) for the few-hundred-row problems (head,
 //                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
+//                  7: one compute wave per SIMD, 160x256, one tile per block (gemm_q4_kernel; experiment)
 template <typename T, int EPI>
 hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
   switch (variant) {
@@ -1131,6 +1292,11 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 4: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     case 5: return launch_deep<T, EPI, 64, 64, 2, 2>(a, s);
     case 6: return launch_simple<T, EPI, 64, 64, 2, 2>(a, s);
+    case 7:  // one compute wave per SIMD (experiment): residual / bias epilogues without LN statistics from LDS
+      if constexpr (EPI == EPI_RESID16 || EPI == EPI_T16_BIAS || EPI == EPI_F32_BIAS)
+        return launch_q4<T, EPI, 160, 256>(a, s);
+      else
+        return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -8,7 +8,7 @@ lib = _lib.load()
 dev = torch.device('cuda:0')
 m, n, k = (int(v) for v in sys.argv[1:4])
 mode = sys.argv[4] if len(sys.argv) > 4 else 'bias'
-lib.oake_debug_set_gemm_variant(4)
+lib.oake_debug_set_gemm_variant(int(sys.argv[5]) if len(sys.argv) > 5 else 4)
 a = (torch.randn(m, k, device=dev) * 0.5).half(); w = (torch.randn(n, k, device=dev) * k ** -0.5).half()
 bias = torch.randn(n, device=dev)
 c = torch.empty(m, n, device=dev, dtype=torch.float32 if mode == 'f32' else torch.float16)
@@ -29,15 +29,17 @@ torch.cuda.synchronize(); e0.record()
 for _ in range(10): run()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
+print(f'M{m} N{n} K{k} {mode}: {us:.1f} us/launch = {2*m*n*k/us/1e6:.0f} TFLOP/s', flush=True)
 trace = torch.zeros(4096 + 512, dtype=torch.int64, device=dev)
 lib.oake_debug_set_gemm_trace(C.c_void_p(trace.data_ptr()))
 run(); torch.cuda.synchronize()
 lib.oake_debug_set_gemm_trace(None)
 wc = trace[4096:].view(256, 2).cpu(); wc = wc[wc[:, 0] > 0]
+if len(wc) == 0:
+    sys.exit(0)  # a kernel without cycle stamps
 t = trace[:4096].view(64, 2, 8, 4).cpu()
 span = (wc[:, 1].max() - wc[:, 0].min()).item() / 100.0
 print(f'  wall-clock (100 MHz): first entry -> last exit {span:.1f} us; entry spread {(wc[:,0].max()-wc[:,0].min()).item()/100:.1f} us; exit spread {(wc[:,1].max()-wc[:,1].min()).item()/100:.1f} us; per-block durations min/mean/max {((wc[:,1]-wc[:,0]).min().item())/100:.1f}/{((wc[:,1]-wc[:,0]).float().mean().item())/100:.1f}/{((wc[:,1]-wc[:,0]).max().item())/100:.1f} us')
-print(f'M{m} N{n} K{k} {mode}: {us:.1f} us/launch = {2*m*n*k/us/1e6:.0f} TFLOP/s')
 for b in (0, 7, 40):
     for grp in (0, 1):
         rows = t[b, grp]; rows = rows[rows[:, 3] > 0]
