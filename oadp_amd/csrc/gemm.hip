@@ -731,6 +731,10 @@ __global__ __launch_bounds__(512) void gemm_q4_kernel(const T* __restrict__ A, c
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   vec8 bf[2][NI];
   vec8 af[5];
+  // tools/gemm_trace.py (record layout of gemm_pp_kernel); only where the registers allow it
+  unsigned long long* const trace = EPI == EPI_RESID16 ? tmap.trace : nullptr;
+  const unsigned long long t_entry = trace ? __builtin_readcyclecounter() : 0;
+  if (trace != nullptr && tid == 0) trace[4096 + (blockIdx.x & 255) * 2] = wall_clock64();
   OAKE_Q4_BAR();  // barrier 0
   {
     const char* st = smem;
@@ -740,6 +744,7 @@ __global__ __launch_bounds__(512) void gemm_q4_kernel(const T* __restrict__ A, c
     af[1] = *reinterpret_cast<const vec8*>(st + a_off + 16 * kRowBytes + kx0);
   }
   int stage = 0;
+  const unsigned long long t_loop = trace ? __builtin_readcyclecounter() : 0;
   for (int g = 0; g < nk; ++g) {
     if (g > 0) OAKE_Q4_BAR();  // barrier g (the fragments prefetched for this K-tile are already in flight)
     const char* st = smem + stage * kStageBytes;
@@ -777,8 +782,15 @@ __global__ __launch_bounds__(512) void gemm_q4_kernel(const T* __restrict__ A, c
     stage = nstage;
   }
 #undef OAKE_Q4_BAR
+  const unsigned long long t_ep = trace ? __builtin_readcyclecounter() : 0;
   tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + fr, n0 + wn * TN, fg, M, N, ep, false,
                                     m0 + BM <= M && n0 + BN <= N, elds, wn * TN, fr);
+  if (trace != nullptr && tid == 0 && blockIdx.x < 64) {
+    unsigned long long* tr = trace + ((size_t)blockIdx.x * 2 * 8) * 4;
+    tr[0] = t_entry; tr[1] = t_loop; tr[2] = t_ep; tr[3] = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    trace[4096 + (blockIdx.x & 255) * 2 + 1] = wall_clock64();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
