@@ -1,21 +1,36 @@
-"""bench.py — OAKE images/sec for ViT-B/32 encode_image at 224^2, batch 256 per GPU.
+"""bench.py — OAKE throughput on MI355X: images/sec of the CLIP ViT-B/32 feature-extraction hot path.
 
-A "step" is one pass of the hot path (oadp.oake.globals' encode_image + fused L2-normalise + fp16
-cast) over one batch of 256 synthetic device-resident 3x224x224 crops, random-init ViT-B/32 weights.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode globals|blocks|objects]
+
+A "step" is one pass of the hot path over one batch of synthetic, device-resident input with
+random-init ViT-B/32 weights:
+
+  globals  (BASELINE.json configs[1], the headline line; default)  encode_image + L2-normalise + fp16
+           over 256 crops of 3x224x224                      [REF oadp/oake/globals.py:57-59]
+  blocks   (configs[2])  64 uint8 RGB images -> image pyramid + 224x224 block crops on the device
+           (Pillow-exact) -> encode_image of every crop     [REF oadp/oake/blocks.py:89-135]
+  objects  (configs[3])  images x 300 synthetic proposals -> expand / mask index math on the host,
+           crops on the device -> dual-stream visual(objects, masks), mini-batches of 512
+                                                             [REF oadp/oake/objects.py:157-186,316-338]
+
 Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU, images sharded, no data-path
-collective; RCCL only for the barrier, the max-over-ranks time and the counters gather.
+collective; RCCL only for the barrier, the max-over-ranks time and the counters gather
+[REF oadp/oake/base.py:122-126, README.md:197-207: torchrun --nproc_per_node=${GPUS}].
+`python bench.py --gpus N` with N > 1 outside a launcher re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE = 8_817_623_040          # BASELINE.md §3 (2 FLOP/MAC; LN/softmax/GELU/bias excluded)
 # The library runs the last block's query / attention output / out_proj / MLP for the CLS row only
@@ -23,126 +38,436 @@ FLOP_PER_IMAGE = 8_817_623_040          # BASELINE.md §3 (2 FLOP/MAC; LN/softma
 # are not executed.  Roofline fractions are quoted on the FLOPs that ARE executed.
 FLOP_SKIPPED_LAST_BLOCK = 49 * (2 * 2 * 768 * 768 + 2 * 2 * 768 * 3072) + 4 * 49 * 50 * 64 * 12
 FLOP_PER_IMAGE_EXECUTED = FLOP_PER_IMAGE - FLOP_SKIPPED_LAST_BLOCK
+FLOP_PER_OBJECT_CROP = 33_552_184_320   # minimal-necessary work of one objects-mode crop
 PEAK_MFMA_DENSE = 2.5e15                # MI355X bf16/f16 dense (MI355X_MICROARCH.md)
 
+# Launcher plumbing check for boxes without a GPU (tests/test_bench_launch.py): every GPU call is
+# skipped, the line says so and carries no throughput.  Never set on a GPU box.
+DRY_PLUMBING = os.environ.get('OAKE_BENCH_DRY_PLUMBING', '') not in ('', '0')
 
-def cpu_baseline(sd, seconds: float = 12.0) -> dict:
-    """The oracle's fp32 torch-CPU encode_image (a PORT/restatement: the reference's `clip` fork is
-    not importable anywhere — SURVEY.md §8c) on a bounded sample of the same workload."""
-    from oadp_amd.weights import synthetic_images
-    from oracle.vit_ref import ViTConfig, encode_image_ref, l2_normalize
-    bs = 32
-    x = synthetic_images(bs, seed=5)
-    cfg = ViTConfig()
-    threads = torch.get_num_threads()
-    l2_normalize(encode_image_ref(sd, cfg, x[:4]))  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        l2_normalize(encode_image_ref(sd, cfg, x)).half()
-        n += bs
+
+# ------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _relaunch(n: int) -> int:
+    """--gpus N outside a launcher: one process per GPU under torch.distributed.run, as the driver does."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__),
+           *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------ workloads
+def _synthetic_u8_images(n: int, w: int, h: int, dev, seed: int):
+    """uint8 HWC images: smooth gradients + noise (JPEG-like statistics), resident on the device."""
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    base = torch.stack([xx * 255 // max(w - 1, 1), yy * 255 // max(h - 1, 1),
+                        (xx + yy) * 255 // max(w + h - 2, 1)], dim=-1)
+    out = []
+    for _ in range(n):
+        noise = torch.randint(-40, 41, (h, w, 3), generator=g)
+        img = (base + noise).clamp_(0, 255).to(torch.uint8)
+        out.append(img if dev is None else img.to(dev))
+    return out
+
+
+def _synthetic_proposals(n_images: int, k: int, w: int, h: int, seed: int):
+    """cx,cy ~ U(image), w,h ~ LogU(8, min(W,H)), clipped; objectness ~U(0,1) sorted
+    descending.  list of float32 [k,5] arrays (x1,y1,x2,y2,score), the proposal pkl's layout."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_images):
+        cx, cy = rng.uniform(0, w, k), rng.uniform(0, h, k)
+        lo, hi = np.log(8.0), np.log(float(min(w, h)))
+        bw, bh = np.exp(rng.uniform(lo, hi, k)), np.exp(rng.uniform(lo, hi, k))
+        x1, y1 = np.clip(cx - bw / 2, 0, w), np.clip(cy - bh / 2, 0, h)
+        x2, y2 = np.clip(cx + bw / 2, 0, w), np.clip(cy + bh / 2, 0, h)
+        score = np.sort(rng.uniform(0, 1, k))[::-1]
+        out.append(np.stack([x1, y1, x2, y2, score], 1).astype(np.float32))
+    return out
+
+
+class _Work:
+    """One mode's step + accounting.  `units` = images, `crops` = encoder rows per step."""
+    flop_per_crop = FLOP_PER_IMAGE_EXECUTED
+    flop_model_per_crop = FLOP_PER_IMAGE
+
+    def __init__(self, args, dev, rank, sd):
+        self.args, self.dev, self.rank, self.sd = args, dev, rank, sd
+
+
+class GlobalsWork(_Work):
+    name = 'globals'
+
+    def build(self, model):
+        import torch
+        a = self.args
+        g = torch.Generator(device=self.dev).manual_seed(1234 + self.rank)
+        self.images = torch.randn(a.batch, 3, 224, 224, generator=g, device=self.dev)  # resident in HBM
+        self.units = self.crops = a.batch
+        cls_note = ('' if os.environ.get('OAKE_CLS_LAST') == '0' else
+                    '; last block evaluated for the CLS rows only (the rows ln_post reads: identical '
+                    'embeddings, 6.6 % fewer FLOPs; OAKE_CLS_LAST=0 runs every row)')
+        self.workload = ('oadp.oake.globals: ViT-B/32 encode_image + L2-normalise + fp16, single 224^2 crop '
+                         f'per image, batch {a.batch} per GPU, random-init weights, device-resident N(0,1) '
+                         'inputs' + cls_note)
+
+    def step(self, model):
+        import torch
+        return model.encode_image(self.images, normalize=True, out_dtype=torch.float16)
+
+    def cpu_baseline(self, seconds: float = 12.0) -> dict:
+        """The oracle's fp32 torch-CPU encode_image (a PORT/restatement: the reference's `clip` fork is
+        not importable anywhere — SURVEY.md §8c) on a bounded sample of the same workload."""
+        import torch
+        from oadp_amd.weights import synthetic_images
+        from oracle.vit_ref import ViTConfig, encode_image_ref, l2_normalize
+        bs = 32
+        x = synthetic_images(bs, seed=5)
+        cfg = ViTConfig()
+        l2_normalize(encode_image_ref(self.sd, cfg, x[:4]))  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            l2_normalize(encode_image_ref(self.sd, cfg, x)).half()
+            n += bs
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 256:
+                break
+        return {'value': round(n / dt, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'sample': f'{n} synthetic 3x224x224 images in batches of {bs}, fp32 torch-CPU oracle, {dt:.1f} s'}
+
+
+class BlocksWork(_Work):
+    name = 'blocks'
+
+    def build(self, model):
+        import itertools
+
+        import torch
+        from oadp_amd.oake import blocks
+        a = self.args
+        w, h = a.image_wh
+        self.ds = blocks.Dataset.__new__(blocks.Dataset)  # index math only (no annotation file)
+        self.ds._r, self.ds._s, self.ds._rescale = 224, 112, 1.5
+        self.images = _synthetic_u8_images(a.batch, w, h, self.dev, seed=77 + self.rank)
+        self.per_image = 1 + len(self.ds._level_tiles(w, h))
+        self.units, self.crops = a.batch, a.batch * self.per_image
+        self._product = itertools.product
+        self.buf = [torch.empty((self.crops, 3, 224, 224), dtype=torch.float16, device=self.dev)
+                    for _ in range(a.lanes)]
+        levels = len({t[2] for t in self.ds._level_tiles(w, h)})
+        self.workload = (f'oadp.oake.blocks: {a.batch} synthetic uint8 {w}x{h} images per GPU (device-resident) -> '
+                         f'{levels}-level pyramid (Pillow-exact bicubic on the GPU) + {self.per_image} crops per image '
+                         f'(block 0 = whole image) -> ViT-B/32 encode_image + L2-normalise + fp16 of all '
+                         f'{self.crops} crops, encoder batches of {a.max_batch}; random-init weights')
+
+    def _device_blocks(self, v, image_u8, out):
+        # oadp_amd/oake/blocks.py::Validator._device_blocks on a bare dataset object
+        import torch
+        ds, level = self.ds, image_u8
+        h, w = level.shape[:2]
+        bboxes = [((w - h) / 2, 0, h, h) if w > h else (0, (h - w) / 2, w, w)]
+        v.crop_resize_normalize(level, [(0, 0, w, h)], out_dtype=torch.float16, out=out[0:1])
+        r, i, scale = ds._r, 1, 1.0
+        while True:
+            tiles = list(self._product(ds._partition(w), ds._partition(h)))
+            if not tiles:
+                break
+            bboxes.extend(ds._bbox(scale, x, y) for x, y in tiles)
+            v.crop_normalize(level, [(x, y, x + r, y + r) for x, y in tiles], out_dtype=torch.float16,
+                             out=out[i:i + len(tiles)])
+            i += len(tiles)
+            w, h = int(w / ds._rescale), int(h / ds._rescale)
+            scale *= ds._rescale
+            level = v.resize_u8(level, (w, h))
+        return bboxes
+
+    def step(self, model):
+        import torch
+        v, buf, k = model.visual, self.buf[model.visual.lane % len(self.buf)], self.per_image
+        for j, im in enumerate(self.images):
+            bboxes = self._device_blocks(v, im, buf[j * k:(j + 1) * k])
+        assert len(bboxes) == k
+        return model.encode_image(buf, normalize=True, out_dtype=torch.float16)
+
+    def cpu_baseline(self, seconds: float = 15.0) -> dict:
+        """Reference-style CPU path of the same workload: PIL pyramid + crops + the fp32 oracle encoder."""
+        import PIL.Image
+        import torch
+        from oracle import crops_ref
+        from oracle.vit_ref import ViTConfig, encode_image_ref, l2_normalize
+        w, h = self.args.image_wh
+        cfg = ViTConfig()
+        imgs = _synthetic_u8_images(2, w, h, None, seed=5)
+        n, crops, t0 = 0, 0, time.perf_counter()
+        for im in imgs:
+            pil = PIL.Image.fromarray(im.numpy(), 'RGB')
+            blocks = [torch.from_numpy(crops_ref.preprocess_ref(pil))]
+            level, scale = pil, 1.0
+            for lw, lh, _ in crops_ref.pyramid_sizes(w, h):
+                if level.size != (lw, lh):
+                    level = level.resize((lw, lh))
+                for x in crops_ref.partition(lw):
+                    for y in crops_ref.partition(lh):
+                        blocks.append(torch.from_numpy(crops_ref.preprocess_ref(level.crop((x, y, x + 224, y + 224)))))
+                if time.perf_counter() - t0 > seconds and n:
+                    break
+            x = torch.stack(blocks)
+            for i in range(0, x.shape[0], 32):
+                l2_normalize(encode_image_ref(self.sd, cfg, x[i:i + 32])).half()
+                if time.perf_counter() - t0 > 2 * seconds:
+                    break
+            n += 1
+            crops += x.shape[0]
+            if time.perf_counter() - t0 > seconds:
+                break
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 256:
-            break
-    return {'value': round(n / dt, 2), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} synthetic 3x224x224 images in batches of {bs}, fp32 torch-CPU oracle, '
-                      f'{dt:.1f} s'}
+        return {'value': round(n / dt, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'sample': f'{n} synthetic {w}x{h} image(s) = {crops} crops: PIL pyramid + crops + fp32 torch-CPU '
+                          f'oracle encoder, {dt:.1f} s'}
 
 
-def main() -> None:
+class ObjectsWork(_Work):
+    name = 'objects'
+    flop_per_crop = FLOP_PER_OBJECT_CROP
+    flop_model_per_crop = 41_546_735_616  # as the reference executes it (BASELINE.md §3)
+
+    def build(self, model):
+        import torch
+        from oadp_amd.oake import objects
+        a = self.args
+        w, h = a.image_wh
+        v = model.visual  # the reference's surgery, objects.py:285-314 (oadp_amd/oake/objects.py::_build_model)
+        v.positional_embedding = v.interpolate_positional_embedding((v.grid * 2,) * 2)
+        v.grid *= 2
+        v.conv1.stride = tuple(s // 2 for s in v.conv1.stride)
+        v.conv1.padding = ((v.patch_size - 1) // 2,) * 2
+        v.object_stream = True
+        self.ds = objects.COCODataset.__new__(objects.COCODataset)
+        self.ds._grid, self.ds._expand_mode = v.grid, objects.ExpandMode.ADAPTIVE
+        self._indices = objects.indices_min_wh
+        self.images = _synthetic_u8_images(a.batch, w, h, self.dev, seed=177 + self.rank)
+        self.props = [torch.from_numpy(p) for p in _synthetic_proposals(a.batch, a.proposals, w, h, 99 + self.rank)]
+        self.wh = torch.tensor([w, h])
+        self.units = a.batch
+        self.crops = sum(int(self._indices(p[:, :4], (4, 4)).sum()) for p in self.props)
+        self.workload = (f'oadp.oake.objects: {a.batch} synthetic uint8 {w}x{h} images per GPU x {a.proposals} '
+                         f'synthetic proposals (SURVEY §8d) -> expand / 14x14 masks on the host, crops on the GPU '
+                         f'(Pillow-exact) -> dual-stream visual(objects, masks) + L2-normalise + fp16, '
+                         f'mini-batches of {a.max_batch}; {self.crops} crops per step; random-init weights')
+
+    def step(self, model):
+        import torch
+        v, ds, mb = model.visual, self.ds, self.args.max_batch
+        objs, masks = [], []
+        for im, p in zip(self.images, self.props):
+            prop = p[:, :4]
+            prop = prop[self._indices(prop, (4, 4))]
+            boxes = ds._expand(prop, self.wh)
+            fg = prop - torch.cat([boxes[:, :2], boxes[:, :2]], dim=1)
+            masks.append(ds._masks(fg, boxes))
+            objs.append(v.crop_resize_normalize(im, boxes, out_dtype=torch.float16))
+        objs = torch.cat(objs)
+        masks = torch.cat(masks).to(self.dev, non_blocking=True).half()
+        embs = [v(objs[i:i + mb], masks[i:i + mb], normalize=True, out_dtype=torch.float16)
+                for i in range(0, objs.shape[0], mb)]
+        return torch.cat(embs)
+
+    def cpu_baseline(self, seconds: float = 15.0) -> dict:
+        """Reference-style CPU path: PIL crops + the fp32 oracle dual-stream encoder, a few proposals."""
+        import PIL.Image
+        import torch
+        from oracle import crops_ref
+        from oracle.vit_ref import ViTConfig, encode_objects_ref, l2_normalize
+        w, h = self.args.image_wh
+        cfg = ViTConfig(stride=16, padding=15)
+        sd = dict(self.sd)
+        from oadp_amd.clip.model import VisionTransformer
+        holder = type('P', (), {'positional_embedding': sd['visual.positional_embedding']})()
+        sd['visual.positional_embedding'] = VisionTransformer.interpolate_positional_embedding(holder, (14, 14))
+        pil = PIL.Image.fromarray(_synthetic_u8_images(1, w, h, None, seed=5)[0].numpy(), 'RGB')
+        prop = torch.from_numpy(_synthetic_proposals(1, self.args.proposals, w, h, 5)[0])[:, :4]
+        boxes = self.ds._expand(prop, self.wh)
+        fg = prop - torch.cat([boxes[:, :2], boxes[:, :2]], dim=1)
+        masks = self.ds._masks(fg, boxes)
+        n, t0, bs = 0, time.perf_counter(), 2
+        while n < prop.shape[0]:
+            o = torch.stack([torch.from_numpy(crops_ref.preprocess_ref(pil.crop(tuple(float(c) for c in b))))
+                             for b in boxes[n:n + bs].tolist()])
+            l2_normalize(encode_objects_ref(sd, cfg, o, masks[n:n + bs])).half()
+            n += o.shape[0]
+            if time.perf_counter() - t0 > seconds:
+                break
+        dt = time.perf_counter() - t0
+        return {'value': round(n / dt / self.args.proposals, 5), 'unit': 'images/sec',
+                'cores': torch.get_num_threads(), 'kind': 'port', 'crops_per_sec': round(n / dt, 3),
+                'sample': f'{n} of the {self.args.proposals} proposal crops of one synthetic {w}x{h} image: PIL crops + '
+                          f'fp32 torch-CPU oracle dual-stream encoder in batches of {bs}, {dt:.1f} s; value = crops/s / '
+                          f'{self.args.proposals} proposals per image'}
+
+
+WORKS = {'globals': GlobalsWork, 'blocks': BlocksWork, 'objects': ObjectsWork}
+DEFAULT_BATCH = {'globals': 256, 'blocks': 64, 'objects': 8}
+DEFAULT_MAX_BATCH = {'globals': None, 'blocks': 512, 'objects': 512}
+
+
+def _profile_files(mode: str) -> tuple[str, str]:
+    tag = '' if mode == 'globals' else f'{mode}_'
+    return (os.path.join(ROOT, 'profiles', f'r02_{tag}hbm_traffic.json'),
+            os.path.join(ROOT, 'profiles', f'r02_{tag}rocprofv3_kernel_stats.csv'))
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--mode', choices=sorted(WORKS), default='globals')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='units per step per GPU: crops (globals, 256), images (blocks 64, objects 8)')
+    ap.add_argument('--image-size', default='640x480', help='blocks / objects: WxH of the synthetic images '
+                    '(1700x1134 walks all 5 pyramid levels: 245 crops per image)')
+    ap.add_argument('--proposals', type=int, default=300, help='objects: proposals per image')
+    ap.add_argument('--max-batch', type=int, default=None, help='encoder batch (objects: the mini_batch_size, 512)')
     ap.add_argument('--dtype', choices=['f16', 'bf16'], default=os.environ.get('OAKE_DTYPE', 'f16'))
     ap.add_argument('--residual', choices=['f16', 'f32'], default='f16',
                     help='residual-stream element type (f16 = compute dtype, as the reference GPU model)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return _relaunch(args.gpus)
+
+    import torch
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     dist = world > 1
-    torch.cuda.set_device(local % torch.cuda.device_count())
-    dev = torch.device('cuda', local % torch.cuda.device_count())
+    backend = os.environ.get('OAKE_BENCH_BACKEND', 'nccl')  # nccl IS RCCL on ROCm; gloo: two ranks may share a GPU
+    if DRY_PLUMBING:
+        dev, backend = torch.device('cpu'), 'gloo'
+    else:
+        ngpu = torch.cuda.device_count()
+        if backend == 'nccl' and world > max(ngpu, 1):
+            raise SystemExit(f'--gpus {world} but only {ngpu} GPU(s) visible')
+        torch.cuda.set_device(local % ngpu)
+        dev = torch.device('cuda', local % ngpu)
     if dist:
         import torch.distributed as td
-        # RCCL on ROCm; OAKE_BENCH_BACKEND=gloo lets two ranks share one GPU to exercise this path on a 1-GPU box
-        td.init_process_group(backend=os.environ.get('OAKE_BENCH_BACKEND', 'nccl'))
+        td.init_process_group(backend=backend)
+        assert td.get_world_size() == args.gpus, (td.get_world_size(), args.gpus)
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        td.all_reduce(ones)  # the collective library itself sees N ranks
+        assert int(ones.item()) == args.gpus, f'all_reduce over {backend} counted {ones.item()} ranks'
 
-    from oadp_amd import _lib, clip
-    from oadp_amd.weights import synthetic_state_dict
-    if 'OAKE_GEMM_VARIANT' in os.environ:  # A/B runs of the GEMM tile configurations
-        _lib.load().oake_debug_set_gemm_variant(int(os.environ['OAKE_GEMM_VARIANT']))
-    if 'OAKE_CLS_LAST' in os.environ:  # 0: run the last block for every token, as the reference does
-        _lib.load().oake_debug_set_cls_last(int(os.environ['OAKE_CLS_LAST']))
-    if 'OAKE_ATTN_VARIANT' in os.environ:
-        _lib.load().oake_debug_set_attention_variant(int(os.environ['OAKE_ATTN_VARIANT']))
-    cdt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
-    sd = synthetic_state_dict()
-    model, _ = clip.load(sd, compute_dtype=cdt, max_batch=args.batch,
-                         residual_dtype=torch.float32 if args.residual == 'f32' else None)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.randn(args.batch, 3, 224, 224, generator=g, device=dev)  # resident in HBM
+    def sync():
+        if not DRY_PLUMBING:
+            torch.cuda.synchronize()
 
-    # consecutive steps alternate over two lanes = (native handle, HIP stream) pairs: a step is still one
-    # pass over one batch of 256, but the kernels of step k+1 fill the start-up / tail bubbles of step k
+    args.batch = args.batch or DEFAULT_BATCH[args.mode]
+    args.max_batch = args.max_batch or DEFAULT_MAX_BATCH[args.mode] or args.batch
+    args.image_wh = tuple(int(v) for v in args.image_size.lower().split('x'))
+    args.lanes = max(1, int(os.environ.get('OAKE_BENCH_LANES', 2)))
+
+    sd = None
+    model = None
+    work = WORKS[args.mode](args, dev, rank, None)
+    if not DRY_PLUMBING:
+        from oadp_amd import clip
+        from oadp_amd.weights import synthetic_state_dict
+        cdt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
+        sd = synthetic_state_dict()
+        work.sd = sd
+        model, _ = clip.load(sd, compute_dtype=cdt, max_batch=args.max_batch,
+                             residual_dtype=torch.float32 if args.residual == 'f32' else None)
+        # A/B switches (per model: oake_set_option on every lane's handle).  OAKE_CLS_LAST=0 runs the last
+        # block for every token, as the reference does; OAKE_GEMM_VARIANT forces a GEMM tile configuration.
+        for env, opt in (('OAKE_GEMM_VARIANT', 'gemm_variant'), ('OAKE_CLS_LAST', 'cls_last'),
+                         ('OAKE_ATTN_VARIANT', 'attention_variant')):
+            if env in os.environ:
+                model.visual.set_option(opt, int(os.environ[env]))
+        work.build(model)
+    else:
+        work.units = work.crops = args.batch
+        work.workload = 'DRY PLUMBING (no GPU work): launcher / rendezvous / counters-gather check only'
+
+    # consecutive steps alternate over lanes = (native handle, HIP stream) pairs: a step is still one
+    # pass over one batch, but the kernels of step k+1 fill the start-up / tail bubbles of step k
     # (OAKE_BENCH_LANES=1: one stream, every kernel of a step strictly after the previous step's)
-    n_lanes = max(1, int(os.environ.get('OAKE_BENCH_LANES', 2)))
-    lane_streams = [torch.cuda.Stream(dev) for _ in range(n_lanes)]
+    n_lanes = args.lanes
+    lane_streams = [torch.cuda.Stream(dev) for _ in range(n_lanes)] if not DRY_PLUMBING else []
     step_no = [0]
 
     def step():
+        if DRY_PLUMBING:
+            time.sleep(0.001)
+            return torch.zeros(1)
         lane = step_no[0] % n_lanes
         step_no[0] += 1
         model.visual.lane = lane
         try:
             with torch.cuda.stream(lane_streams[lane]):
-                return model.encode_image(images, normalize=True, out_dtype=torch.float16)
+                return work.step(model)
         finally:
             model.visual.lane = 0
 
     for _ in range(n_lanes):  # set-up, not a step of the contract: create every lane's handle (weights, buffers)
         out = step()
-    torch.cuda.synchronize()
+    sync()
     step_no[0] = 0
     for _ in range(args.warmup):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         td.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         td.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(out.float()).all()
 
-    counters = torch.tensor([args.batch * args.steps, args.batch * args.steps, elapsed,
+    # [images, crops, seconds, bytes of features] — the reference's throughput counters, gathered to rank 0
+    counters = torch.tensor([work.units * args.steps, work.crops * args.steps, elapsed,
                              out.numel() * 2 * args.steps], dtype=torch.float64, device=dev)
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = tmax.item()
         gathered = [torch.zeros_like(counters) for _ in range(world)]
-        td.all_gather(gathered, counters)  # the one RCCL exchange: 32 B per rank
-        total_images = sum(c[0].item() for c in gathered)
+        td.all_gather(gathered, counters)  # the one data-free exchange: 32 B per rank
+        total_units = sum(c[0].item() for c in gathered)
+        total_crops = sum(c[1].item() for c in gathered)
+        ranks_seen = len(gathered)
     else:
-        total_images = counters[0].item()
+        total_units, total_crops, ranks_seen = counters[0].item(), counters[1].item(), 1
 
     roofline = None
     kernels = None
-    if rank == 0 and not args.no_profile:
-        torch.cuda.synchronize()
+    if rank == 0 and not args.no_profile and not DRY_PLUMBING:
+        sync()
+        n_prof = 3 if args.mode == 'globals' else 1
         model.visual.profile(True)  # (lane 0's handle, on the current stream: kernels one after another)
-        for _ in range(3):
-            model.encode_image(images, normalize=True, out_dtype=torch.float16)
+        for _ in range(n_prof):
+            work.step(model)
         prof = model.visual.profile_read()
         model.visual.profile(False)
         gemms = [p for p in prof if p['flops'] > 0 and p['name'].startswith('gemm')]
@@ -153,60 +478,82 @@ def main() -> None:
             'achieved': round(achieved, 1), 'peak': PEAK_MFMA_DENSE / 1e12, 'unit': 'TFLOP/s',
             'frac': round(achieved * 1e12 / PEAK_MFMA_DENSE, 4),
             'avg_launch_us': round(dom['total_ms'] * 1e3 / dom['launches'], 2),
+            'algorithmic_gflop_per_launch': round(dom['flops'] / dom['launches'] / 1e9, 3),
+            'timing': 'live: HIP kernel begin/end stamps on the launch stream (hipExtLaunchKernelGGL events), one lane',
             'traffic': None,
         }
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes over this same command
-        # (tools/pmc_traffic.py -> profiles/hbm_traffic.json); PMC cannot be sampled from in here.
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath) and args.batch == 256 and args.dtype == 'f16':
-            rec = json.load(open(tpath)).get(dom['name'])
+        # HBM bytes per launch cannot be sampled from inside this process: they come from separate
+        # rocprofv3 --pmc passes over this same command (tools/pmc_traffic.py), committed under profiles/
+        # together with the session they were measured in.  Reported only for the matching configuration
+        # and always labelled as not-live.
+        tpath, spath = _profile_files(args.mode)
+        default_cfg = (args.batch == DEFAULT_BATCH[args.mode] and args.dtype == 'f16'
+                       and args.image_size == '640x480' and args.proposals == 300)
+        if os.path.exists(tpath) and default_cfg:
+            tj = json.load(open(tpath))
+            rec = tj.get(dom['name'])
             if rec:
                 roofline['traffic'] = rec['hbm_bytes_per_launch']
-                roofline['traffic_unit'] = 'bytes/launch (PMC, profiles/hbm_traffic.json)'
-        # the committed rocprofv3 --kernel-trace --stats summary of this same command, for comparison
-        # (kernel begin/end stamps of consecutive launches include the hand-over between kernels, which
-        # rocprofv3's per-dispatch interval does not: expect the live number a few % higher)
-        spath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_rocprofv3_kernel_stats.csv')
-        rec = (json.load(open(tpath)).get(dom['name']) or {}) if os.path.exists(tpath) else {}
-        if os.path.exists(spath) and rec.get('kernel') and args.batch == 256 and args.dtype == 'f16':
-            import csv
-            for row in csv.DictReader(open(spath)):
-                if row['Name'] == rec['kernel']:
-                    roofline['avg_launch_us_rocprofv3'] = round(float(row['AverageNs']) / 1e3, 2)
-                    roofline['rocprofv3_summary'] = 'profiles/r01_rocprofv3_kernel_stats.csv'
+                roofline['traffic_unit'] = 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)'
+                roofline['traffic_source'] = {'file': os.path.relpath(tpath, ROOT), 'live': False,
+                                              'session': tj.get('_session', 'unknown')}
+                if os.path.exists(spath) and rec.get('kernel'):
+                    import csv
+                    for row in csv.DictReader(open(spath)):
+                        if row['Name'] == rec['kernel']:
+                            roofline['avg_launch_us_rocprofv3'] = round(float(row['AverageNs']) / 1e3, 2)
+                            roofline['rocprofv3_summary'] = {'file': os.path.relpath(spath, ROOT), 'live': False,
+                                                             'session': tj.get('_session', 'unknown')}
         tot_ms = sum(p['total_ms'] for p in prof)
-        kernels = {p['name']: {'ms_per_step': round(p['total_ms'] / 3, 4),
+        kernels = {p['name']: {'ms_per_step': round(p['total_ms'] / n_prof, 4),
                                'share': round(p['total_ms'] / tot_ms, 4),
                                'tflops': round(p['flops'] / (p['total_ms'] * 1e-3) / 1e12, 1) if p['flops'] else None}
                    for p in sorted(prof, key=lambda p: -p['total_ms'])}
 
     if rank == 0:
-        value = total_images / elapsed
-        flop_image = FLOP_PER_IMAGE if os.environ.get('OAKE_CLS_LAST') == '0' else FLOP_PER_IMAGE_EXECUTED
+        value = total_units / elapsed
+        crops_per_s = total_crops / elapsed
+        flop_crop = work.flop_per_crop
+        if args.mode != 'objects' and os.environ.get('OAKE_CLS_LAST') == '0':
+            flop_crop = FLOP_PER_IMAGE
+        one_lane = None
+        if args.mode == 'globals' and world == 1 and n_lanes > 1 and not DRY_PLUMBING and not args.no_profile:
+            # the same step on ONE lane / stream (every kernel strictly after the previous step's)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(max(4, args.steps // 2)):
+                work.step(model)
+            sync()
+            one_lane = round(work.units * max(4, args.steps // 2) / (time.perf_counter() - t1), 1)
+        metric = {'globals': 'OAKE images/sec (ViT-B/32, 224^2, bs256)',
+                  'blocks': 'OAKE images/sec (blocks mode: pyramid block crops per image, ViT-B/32)',
+                  'objects': 'OAKE images/sec (objects mode: proposal crops per image, dual-stream ViT-B/32)'}[args.mode]
         line = {
-            'metric': 'OAKE images/sec (ViT-B/32, 224^2, bs256)', 'value': round(value, 1),
+            'metric': metric, 'value': None if DRY_PLUMBING else round(value, 3 if value < 100 else 1),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'oadp.oake.globals: ViT-B/32 encode_image + L2-normalise + fp16, '
-                                   f'single 224^2 crop per image, batch {args.batch} per GPU, '
-                                   'random-init weights, device-resident N(0,1) inputs'
-                                   + ('' if os.environ.get('OAKE_CLS_LAST') == '0' else
-                                      '; last block evaluated for the CLS rows only (the rows ln_post reads: '
-                                      'identical embeddings, 6.6 % fewer FLOPs; OAKE_CLS_LAST=0 runs every row)'),
-                       'batch_per_gpu': args.batch, 'sharding': f'images x{world} (no data-path collective)',
-                       'hip_streams': n_lanes},
-            'mfma_roofline_frac_e2e': round(value / world * flop_image / PEAK_MFMA_DENSE, 4),
-            'flop_per_image': {'model': FLOP_PER_IMAGE, 'executed': flop_image},
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'dry-run plumbing check, no GPU work' if DRY_PLUMBING else 'synthetic',
+            'config': {'workload': work.workload, 'mode': args.mode, 'batch_per_gpu': args.batch,
+                       'crops_per_step_per_gpu': work.crops,
+                       'sharding': f'images x{world} (no data-path collective; ranks gathered: {ranks_seen})',
+                       'launcher': 'torch.distributed.run, one process per GPU' if dist else 'single process',
+                       'backend': backend if dist else None, 'hip_streams': n_lanes},
+            'crops_per_sec': None if DRY_PLUMBING else round(crops_per_s, 1),
+            'mfma_roofline_frac_e2e': None if DRY_PLUMBING else round(crops_per_s / world * flop_crop / PEAK_MFMA_DENSE, 4),
+            'flop_per_crop': {'model': work.flop_model_per_crop, 'executed': flop_crop},
+            'one_lane_images_per_sec': one_lane,
             'roofline': roofline,
             'kernels': kernels,
             # (rank 0 at N=1 only: with more ranks the other processes would sit in teardown for its 10+ s)
-            'cpu_baseline': None if (args.no_cpu_baseline or world > 1) else cpu_baseline(sd),
+            'cpu_baseline': (None if (args.no_cpu_baseline or world > 1 or DRY_PLUMBING) else work.cpu_baseline()),
+            'cpu_baseline_note': 'reported on rank 0 at N=1 only' if world > 1 else None,
         }
         print(json.dumps(line), flush=True)
     if dist:
         td.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -23,3 +23,13 @@ batch_size = 256
 # (files are read by the main process, Huffman passes run on `decode_threads` native threads;
 # measured 2.8 k images/s for globals and 30 k crops/s for blocks on one GPU, tools/sweep_bench.py)
 decode_threads = 32
+
+# Behaviours of the un-vendored LutingWang/CLIP fork / todd that the reference's sources do not pin
+# (oadp_amd/clip/settings.py).  The values below are our reading of the
+# call sites; flip them here (or with --override .fork.load_default_true:center_crop ...) if the fork
+# says otherwise — no code change needed.
+fork = dict(
+    load_default_true='squash',                                            # clip.load_default(True) transform
+    positional_interpolation=dict(mode='bicubic', align_corners=False),    # visual.interpolate_positional_embedding
+    min_wh_inclusive=True,                                                 # todd BBoxes.indices(min_wh): >= (True) or >
+)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OAKE_ABI_VERSION 1
+#define OAKE_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define OAKE_API __attribute__((visibility("default")))
@@ -76,7 +76,8 @@ typedef struct oake_handle oake_handle;
  * reference's surgery (oadp/oake/objects.py:298-301): stride = 32 // upsample = 16,
  * padding = (32 - 1) // 2 = 15, which makes grid = 14 and 197 tokens.
  * `compute_dtype`: OAKE_F16 (reference GPU dtype, default) or OAKE_BF16 — the 16-bit type fed
- * to the MFMA units; accumulation, LayerNorm, softmax and the residual stream are fp32.
+ * to the MFMA units; accumulation, LayerNorm statistics and softmax are fp32.  The residual stream
+ * x has its own element type, `residual_dtype` below.
  */
 typedef struct oake_config {
   int32_t image_size;
@@ -148,12 +149,12 @@ OAKE_API int oake_encode_objects(oake_handle* h, const void* d_objects, int in_d
                         void* d_out, int out_dtype, int normalize, void* stream);
 
 /*
- * GPU half of `preprocess(image.crop(box))` for crops that need no resampling or bilinear /
- * bicubic resampling of a uint8 HWC (interleaved RGB) device image: for each of k boxes
- * (x1,y1,x2,y2 int32, PIL crop semantics: zero fill outside the image) produce a
- * [k,3,out,out] NCHW tensor of `out_dtype`, scaled by 1/255 and normalised with mean/std
- * (3 floats each, host pointers).  When the box is exactly out×out the result is bit-exact
- * w.r.t. ToTensor+Normalize in fp32.
+ * GPU half of `preprocess(image.crop(box))` for crops that need NO resampling (the 224x224 blocks
+ * of oadp/oake/blocks.py:79-81) of a uint8 HWC (interleaved RGB) device image: each of the k boxes
+ * (x1,y1,x2,y2 int32, PIL crop semantics: zero fill outside the image) must be exactly
+ * out_size x out_size; the result is a [k,3,out,out] NCHW tensor of `out_dtype`, scaled by 1/255 and
+ * normalised with mean/std (3 floats each, host pointers), bit-exact w.r.t. ToTensor + Normalize in
+ * fp32.  Crops that need resampling go through oake_crop_resize_normalize.
  */
 OAKE_API int oake_crop_normalize(oake_handle* h, const uint8_t* d_image_hwc, int height, int width,
                         const int32_t* d_boxes_xyxy, int k, int out_size,
@@ -289,7 +290,9 @@ OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* str
  * of that kernel, 16 = sequences of at most 64 keys without a causal mask: the two waves of a (crop,
  * head) share its K / V in LDS, staged with LDS-DMA.  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
-/* GEMM configuration: -1 = automatic per shape, 0..7 = forced (see csrc/gemm.hip). */
+/* GEMM configuration: -1 = automatic per shape, 0..8 = forced (see csrc/gemm.hip).
+ * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel
+ * entry points of the calling thread; a handle's own switches are set with oake_set_option. */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
 /* x[m,n] (16-bit, in place) += A * W^T + bias — the residual epilogue of out_proj / c_proj.  On the
  * persistent kernel (large m) d_rowpart [m, 16, 2] fp32 (or NULL) receives (sum, sum of squares) of
@@ -299,13 +302,36 @@ OAKE_API int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const flo
 /* GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside), n < 0 = M slabs of
  * -n tiles (column-major inside). */
 OAKE_API int oake_debug_set_gemm_panel(int panel);
-/* oake_encode_image computes the last block for the CLS rows only (the only rows ln_post reads): K / V
- * projections of all tokens, everything else of that block for one row per image.  0 = run the block for
- * every token as the reference does (A/B runs, tests).  Default 1. */
-OAKE_API int oake_debug_set_cls_last(int enable);
 /* Debug: device buffer of 4608 uint64 receiving per-tile cycle stamps of the production GEMM
  * (entry, tile start, epilogue start, epilogue end; then per-block wall-clock entry/exit), or NULL. */
 OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
+
+
+/*
+ * Per-handle switches (nothing process-wide: two handles / lanes never see each other's settings).
+ *   OAKE_OPT_CLS_LAST           oake_encode_image computes the last block for the CLS rows only (the only
+ *                               rows ln_post reads): K / V projections of all tokens, everything else of
+ *                               that block for one row per image.  0 = run the block for every token as
+ *                               the reference does (A/B runs, tests).  Default 1.
+ *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default), 0..8 forced (csrc/gemm.hip)
+ *   OAKE_OPT_GEMM_PANEL         GEMM tile order, as oake_debug_set_gemm_panel.  Default 0.
+ *   OAKE_OPT_ATTENTION_VARIANT  bit set, as oake_debug_set_attention_variant.  Default 31.
+ */
+enum {
+  OAKE_OPT_CLS_LAST = 1,
+  OAKE_OPT_GEMM_VARIANT = 2,
+  OAKE_OPT_GEMM_PANEL = 3,
+  OAKE_OPT_ATTENTION_VARIANT = 4
+};
+OAKE_API int oake_set_option(oake_handle* h, int option, int value);
+OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);
+
+/* Test hook: copy a 16-bit matmul weight back from the device, as uploaded (f32 -> 16 bit; q rows of
+ * in_proj scaled by 1/8; visual.proj / text_projection transposed to [embed, width]).  `name` is the
+ * state-dict key ("visual.conv1.weight", "...attn.in_proj_weight", "...attn.out_proj.weight",
+ * "...mlp.c_fc.weight", "...mlp.c_proj.weight", "visual.proj"); "<key>#folded" reads the gamma-folded
+ * copy of in_proj / c_fc.  numel must match the tensor. */
+OAKE_API int oake_debug_read_weight16(oake_handle* h, const char* name, uint16_t* h_out, size_t numel);
 
 #ifdef __cplusplus
 }

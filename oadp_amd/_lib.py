@@ -9,7 +9,8 @@ import pathlib
 OAKE_OK = 0
 OAKE_ERR_INVALID, OAKE_ERR_HIP, OAKE_ERR_STATE, OAKE_ERR_UNKNOWN_TENSOR, OAKE_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
-ABI_VERSION = 1
+OAKE_OPT_CLS_LAST, OAKE_OPT_GEMM_VARIANT, OAKE_OPT_GEMM_PANEL, OAKE_OPT_ATTENTION_VARIANT = 1, 2, 3, 4
+ABI_VERSION = 2
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library
 LIB_PATH = pathlib.Path(os.environ.get('OAKE_LIB') or pathlib.Path(__file__).resolve().parent / 'liboake_hip.so')
@@ -69,8 +70,10 @@ SIGNATURES = {
     'oake_debug_set_gemm_variant': (_I, [_I]),
     'oake_debug_gemm_resid16': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_set_gemm_panel': (_I, [_I]),
-    'oake_debug_set_cls_last': (_I, [_I]),
     'oake_debug_set_gemm_trace': (_I, [_VP]),
+    'oake_set_option': (_I, [_VP, _I, _I]),
+    'oake_get_option': (_I, [_VP, _I, C.POINTER(_I)]),
+    'oake_debug_read_weight16': (_I, [_VP, C.c_char_p, _VP, C.c_size_t]),
 }
 
 _lib = None

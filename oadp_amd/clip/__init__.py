@@ -4,5 +4,6 @@ that OADP's OAKE path touches: ``load_default`` -> (model, preprocess), ``model.
 from . import model
 from .model import CLIP, VisionTransformer, load, load_default
 from .preprocess import Preprocess
+from .settings import settings
 
-__all__ = ['model', 'CLIP', 'VisionTransformer', 'load', 'load_default', 'Preprocess']
+__all__ = ['model', 'CLIP', 'VisionTransformer', 'load', 'load_default', 'Preprocess', 'settings']

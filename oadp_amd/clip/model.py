@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from .preprocess import Preprocess
+from .settings import settings
 
 _TORCH2OAKE = {torch.float32: _lib.OAKE_F32, torch.float16: _lib.OAKE_F16,
                torch.bfloat16: _lib.OAKE_BF16}
@@ -53,11 +54,78 @@ def _infer_arch(sd: Mapping[str, torch.Tensor]) -> dict:
                 heads=width // 64, mlp_dim=mlp, embed_dim=sd['visual.proj'].shape[1])
 
 
-class VisionTransformer:
+class _RemovableHandle:
+    """What ``nn.Module.register_forward_*hook`` returns: ``.remove()`` unregisters the hook."""
+
+    def __init__(self, hooks: list, hook) -> None:
+        self._hooks, self._hook = hooks, hook
+
+    def remove(self) -> None:
+        if self._hook in self._hooks:
+            self._hooks.remove(self._hook)
+
+
+class _HookPoint:
+    """The forward-hook registration surface of an ``nn.Module``, recording only.
+
+    The reference's objects mode attaches its ``Hooks`` object to ``visual``, ``visual.transformer``
+    and every ``visual.transformer.resblocks[i]`` (oadp/oake/objects.py:303-312).  The native encoder
+    has no Python-level module boundaries to call hooks at; what those particular hooks compute — the
+    object-token stream — is implemented in the library (``oake_encode_objects``).  So hooks are
+    recorded here, and ``VisionTransformer._hook_mode()`` recognises the reference's pattern (and
+    refuses anything else at forward time, loudly)."""
+
+    def __init__(self) -> None:
+        self._forward_pre_hooks: list = []
+        self._forward_hooks: list = []
+
+    def register_forward_pre_hook(self, hook, **kwargs):
+        self._forward_pre_hooks.append(hook)
+        return _RemovableHandle(self._forward_pre_hooks, hook)
+
+    def register_forward_hook(self, hook, **kwargs):
+        self._forward_hooks.append(hook)
+        return _RemovableHandle(self._forward_hooks, hook)
+
+
+class _AttnSpec:
+    """``resblock.attn``: the reference's hook reads ``module.attn.num_heads`` (objects.py:236)."""
+
+    def __init__(self, embed_dim: int, num_heads: int) -> None:
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+
+
+class ResidualAttentionBlock(_HookPoint):
+    """``visual.transformer.resblocks[i]`` as far as the reference touches it: hook registration and
+    ``attn.num_heads``.  The block's arithmetic runs in csrc/{gemm,attention}.hip."""
+
+    def __init__(self, width: int, heads: int, index: int) -> None:
+        super().__init__()
+        self.attn = _AttnSpec(width, heads)
+        self.index = index
+
+
+class Transformer(_HookPoint):
+    """``visual.transformer``: ``resblocks`` (iterable, indexable) + hook registration."""
+
+    def __init__(self, width: int, layers: int, heads: int) -> None:
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = tuple(ResidualAttentionBlock(width, heads, i) for i in range(layers))
+
+
+# method names of the reference's Hooks object, by the hook point they are registered on (objects.py:198-266)
+_OBJECTS_HOOKS = dict(visual_pre='visual_forward_pre', transformer_pre='transformer_forward_pre',
+                      transformer_post='transformer_forward', block_pre='residual_attention_block_forward_pre',
+                      visual_post='visual_forward')
+
+
+class VisionTransformer(_HookPoint):
 
     def __init__(self, state_dict: Mapping[str, torch.Tensor], *, compute_dtype=torch.float16,
                  residual_dtype: torch.dtype | None = None, max_batch: int = 256,
                  device: int | None = None) -> None:
+        super().__init__()
         sd = {k: v.detach().to('cpu', torch.float32).contiguous()
               for k, v in state_dict.items() if k.startswith(VISION_PREFIX)}
         self._sd = sd
@@ -71,8 +139,11 @@ class VisionTransformer:
         self.output_dim = arch['embed_dim']
         self.grid = self.input_resolution // self.patch_size
         self.conv1 = Conv1Spec(self.patch_size)
+        self.transformer = Transformer(self.width, self.layers, self.heads)
         self.positional_embedding = sd['visual.positional_embedding']
-        self.object_stream = False  # set by objects-mode surgery (replaces the reference's Hooks)
+        # The object-token stream of the reference's Hooks.  Switched on either explicitly (our mirror,
+        # oadp_amd/oake/objects.py) or by registering the reference's own hook pattern (_hook_mode).
+        self.object_stream = False
         self.compute_dtype = compute_dtype
         # residual stream x: the compute dtype (as the reference's fp16 GPU model) or float32
         self.residual_dtype = residual_dtype or compute_dtype
@@ -85,31 +156,84 @@ class VisionTransformer:
         # object uses; the caller pairs a lane with a stream (BaseValidator._flush, bench.py).
         self.lane = 0
         self._lanes: dict[int, tuple] = {}
+        self._options: dict[int, int] = {}  # oake_set_option values, applied to every lane's handle
 
     @property
     def _handle(self):
         return self._lanes.get(self.lane, (None, None))[0]
 
+    OPTIONS = dict(cls_last=_lib.OAKE_OPT_CLS_LAST, gemm_variant=_lib.OAKE_OPT_GEMM_VARIANT,
+                   gemm_panel=_lib.OAKE_OPT_GEMM_PANEL, attention_variant=_lib.OAKE_OPT_ATTENTION_VARIANT)
+
+    def set_option(self, name: str, value: int) -> None:
+        """Per-model kernel-selection switch (``oake_set_option`` on every lane's handle, now and for
+        handles created later): cls_last, gemm_variant, gemm_panel, attention_variant."""
+        key = self.OPTIONS[name]
+        self._options[key] = int(value)
+        for h, _ in self._lanes.values():
+            _lib.check(self._lib, h, self._lib.oake_set_option(h, key, int(value)), 'oake_set_option')
+
     # -- reference surface -----------------------------------------------------------------
     def interpolate_positional_embedding(self, size: tuple[int, int]) -> torch.Tensor:
-        """[1 + g*g, C] -> [1 + size[0]*size[1], C]: CLS row kept, grid rows resampled bicubically
-        (align_corners=False).  The fork's own mode is unknown."""
+        """[1 + g*g, C] -> [1 + size[0]*size[1], C]: CLS row kept, grid rows resampled — bicubically
+        with align_corners=False unless ``fork.positional_interpolation`` says otherwise: the fork's own
+        mode is unknown (oadp_amd/clip/settings.py)."""
         pos = self.positional_embedding.float()
         g = int(round((pos.shape[0] - 1) ** 0.5))
         cls, grid = pos[:1], pos[1:].reshape(1, g, g, -1).permute(0, 3, 1, 2)
-        grid = F.interpolate(grid, size=size, mode='bicubic', align_corners=False)
+        pi = settings.positional_interpolation
+        if pi['mode'] == 'nearest':
+            grid = F.interpolate(grid, size=size, mode='nearest')
+        else:
+            grid = F.interpolate(grid, size=size, mode=pi['mode'], align_corners=pi['align_corners'])
         grid = grid.permute(0, 2, 3, 1).reshape(size[0] * size[1], -1)
         return torch.cat([cls, grid])
 
+    def _hook_mode(self) -> str:
+        """'none' (no hooks anywhere), 'objects' (exactly the reference's objects-mode pattern,
+        oadp/oake/objects.py:303-312: a pre-hook on visual, a pre- and a post-hook on transformer, a
+        pre-hook on every block, all methods of one ``Hooks``-like object, identified by name) —
+        anything else raises: arbitrary Python hooks cannot run inside the native encoder."""
+        t = self.transformer
+        points = [('visual_pre', self._forward_pre_hooks), ('visual_post', self._forward_hooks),
+                  ('transformer_pre', t._forward_pre_hooks), ('transformer_post', t._forward_hooks)]
+        points += [('block_pre', b._forward_pre_hooks) for b in t.resblocks]
+        block_post = [h for b in t.resblocks for h in b._forward_hooks]
+        if not block_post and not any(hooks for _, hooks in points):
+            return 'none'
+
+        def only(role, hooks, required=True):
+            if not hooks and not required:
+                return None
+            if len(hooks) != 1 or getattr(hooks[0], '__name__', None) != _OBJECTS_HOOKS[role]:
+                raise NotImplementedError(
+                    f'forward hooks on the native encoder: only the OAKE objects-mode pattern '
+                    f'(reference oadp/oake/objects.py:303-312) is supported; got '
+                    f'{[getattr(h, "__name__", repr(h)) for h in hooks]} where {_OBJECTS_HOOKS[role]!r} belongs')
+            return getattr(hooks[0], '__self__', None)
+
+        if block_post:
+            raise NotImplementedError('forward (post) hooks on resblocks are not part of the objects-mode pattern')
+        owners = {id(only(role, hooks, required=(role != 'visual_post'))) for role, hooks in points
+                  if not (role == 'visual_post' and not hooks)}
+        if len(owners) != 1:
+            raise NotImplementedError('the objects-mode hooks must be methods of ONE Hooks object')
+        return 'objects'
+
+    def _objects_mode(self) -> bool:
+        return self.object_stream or self._hook_mode() == 'objects'
+
     def __call__(self, x: torch.Tensor, masks: torch.Tensor | None = None, *,
                  normalize: bool = False, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+        objects_mode = self._objects_mode()
         if masks is None:
-            if self.object_stream:
+            if objects_mode:
                 raise ValueError('objects-mode model: call visual(objects, masks)')
             return self._forward(x, None, normalize, out_dtype)
-        if not self.object_stream:
-            raise ValueError('visual(x, masks) needs the objects-mode surgery '
-                             '(oadp_amd.oake.objects.Validator._build_model)')
+        if not objects_mode:
+            raise ValueError('visual(x, masks) needs the objects-mode surgery: the reference\'s '
+                             'Validator._build_model (geometry + its Hooks registered on visual / '
+                             'transformer / resblocks) or visual.object_stream = True')
         return self._forward(x, masks, normalize, out_dtype)
 
     forward = __call__
@@ -156,6 +280,8 @@ class VisionTransformer:
             missing = lib.oake_missing_tensors(h)
             if missing:
                 raise ValueError(f'state_dict lacks {missing} vision-tower tensors')
+            for opt, value in self._options.items():
+                _lib.check(lib, h, lib.oake_set_option(h, opt, value), 'oake_set_option')
         except Exception:
             lib.oake_destroy(h)
             raise
@@ -545,16 +671,18 @@ def load(state_dict: Mapping[str, torch.Tensor] | str | os.PathLike, *, squash: 
 
 def load_default(flag: bool = False, **kwargs) -> tuple[CLIP, Preprocess]:
     """``clip.load_default(flag)`` of the fork: ViT-B/32 + its transform.  ``flag`` selects the
-    transform variant (see Preprocess).  Weights: ``$OAKE_CLIP_CHECKPOINT`` or
+    transform variant (see Preprocess; what True means is the ``fork.load_default_true`` setting,
+    oadp_amd/clip/settings.py).  Weights: ``$OAKE_CLIP_CHECKPOINT`` or
     pretrained/clip/ViT-B-32.pt; with ``OAKE_SYNTHETIC_WEIGHTS=1`` (or DRY_RUN=True and no
     checkpoint on disk) the deterministic synthetic ViT-B/32 of oadp_amd.weights is used."""
     path = os.environ.get('OAKE_CLIP_CHECKPOINT', DEFAULT_CHECKPOINT)
     synthetic = os.environ.get('OAKE_SYNTHETIC_WEIGHTS', '') not in ('', '0', 'False')
     dry = os.environ.get('DRY_RUN', '') not in ('', '0', 'False')
+    squash = bool(flag) and settings.load_default_true == 'squash'
     if not synthetic and os.path.exists(path):
-        return load(path, squash=flag, **kwargs)
+        return load(path, squash=squash, **kwargs)
     if synthetic or dry:
         from ..weights import synthetic_state_dict
-        return load(synthetic_state_dict(), squash=flag, **kwargs)
+        return load(synthetic_state_dict(), squash=squash, **kwargs)
     raise FileNotFoundError(f'{path} not found (set OAKE_CLIP_CHECKPOINT, or '
                             'OAKE_SYNTHETIC_WEIGHTS=1 for random-init weights)')

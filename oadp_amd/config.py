@@ -41,7 +41,12 @@ class Config(dict):
     def _load_raw(cls, path: pathlib.Path) -> dict:
         scope: dict[str, Any] = {}
         exec(compile(path.read_text(), str(path), 'exec'), scope)
-        cfg = {k: v for k, v in scope.items() if not k.startswith('__')}
+        # config keys are the public data names of the file: helpers (``_COCO``, ``def _split``), imported
+        # modules and functions are not — they would otherwise travel into Validator(**config)
+        import types
+        cfg = {k: v for k, v in scope.items()
+               if (k == '_base_' or not k.startswith('_'))
+               and not isinstance(v, (types.ModuleType, types.FunctionType, type))}
         bases = cfg.pop('_base_', [])
         if isinstance(bases, str):
             bases = [bases]

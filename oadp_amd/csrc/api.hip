@@ -25,22 +25,15 @@
 #include "kernels.h"
 
 namespace oake {
-hipEvent_t g_launch_start = nullptr, g_launch_stop = nullptr;  // common.h, OAKE_LAUNCH
-extern int g_attention_use_tr;
-extern int g_attention_q32;
-extern int g_attention_coop;
-extern int g_attention_fuse_obj;
-extern int g_attention_pair;
-extern int g_gemm_variant;
-extern int g_gemm_panel;
-extern unsigned long long* g_gemm_trace;
+thread_local hipEvent_t g_launch_start = nullptr, g_launch_stop = nullptr;  // common.h, OAKE_LAUNCH
 }
 
 using namespace oake;
 
 namespace {
-// encode_image: run the last block for the CLS rows only (debug switch: 0 = all rows, as the reference)
-int g_cls_last = 1;
+// Kernel-selection switches of the handle-less oake_debug_* kernel entry points (tests, tools): per
+// calling thread.  Handles carry their own (oake_set_option) and never read these.
+thread_local LaunchOpts t_debug_opts;
 
 
 thread_local std::string g_create_error;
@@ -82,6 +75,9 @@ struct oake_handle {
   int dt16 = DT_F16;
   int xdt = DT_F32;           // residual-stream element type: DT_F32 or dt16
   std::string err;
+  // oake_set_option: this handle's kernel-selection switches (nothing process-wide)
+  LaunchOpts opts;
+  int cls_last = 1;           // encode_image: last block for the CLS rows only (0 = all rows, as the reference)
 
   // weights
   void* conv_w = nullptr;     // [width, 3*P*P] 16-bit
@@ -105,8 +101,9 @@ struct oake_handle {
   void* zero_mask = nullptr;  // [B, L-1] 16-bit zeros: the CLS rows of the last block mask nothing
   bool stat_fused = false;    // this pass: statistics via rowpart (else the rowstat kernel)
   int nparts = 0;             // valid slices per row in rowpart (1 after embed, width/64 after a GEMM)
-  float* e32 = nullptr;       // [B, embed] fp32 head projection
-  void* yn = nullptr;         // [B, C] 16-bit: ln_post output (head input)
+  float* e32 = nullptr;       // [head_rows, embed] fp32 head projection
+  void* yn = nullptr;         // [head_rows, C] 16-bit: ln_post output (head input)
+  int head_rows = 0;          // rows the head buffers (y, yn, e32) hold: the most sequences one pass encodes
 
   // resample scratch (grown on demand)
   ResampleJob* rs_jobs = nullptr;
@@ -443,13 +440,17 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
   A(&h->qkv, R * 3 * C * e16());
   A(&h->att, R * C * e16());
   A(&h->hbuf, R * F * e16());
-  A((void**)&h->y, B * C * 4);
+  // vision: one row per crop.  text: sequences shorter than the context pack more than max_batch per
+  // pass (oake_encode_text), up to this many — the head buffers must hold them all
+  h->head_rows = (int)(text ? B * 4 : B);
+  const size_t HR = (size_t)h->head_rows;
+  A((void**)&h->y, HR * C * 4);
   A((void**)&h->rowstat, (R + 2) * 2 * 4);
   A((void**)&h->rowpart, R * 32 * 4);
   A(&h->zero_mask, B * (L > 1 ? L - 1 : 1) * 2);  // "nothing masked" for the CLS rows of the last block
   if (rc == OAKE_OK && hipMemset(h->zero_mask, 0, B * (L > 1 ? L - 1 : 1) * 2) != hipSuccess) rc = OAKE_ERR_HIP;
-  A((void**)&h->e32, B * E * 4);
-  A(&h->yn, B * C * e16());
+  A((void**)&h->e32, HR * E * 4);
+  A(&h->yn, HR * C * e16());
   if (rc != OAKE_OK) {
     g_create_error = h->err;
     oake_destroy(h);
@@ -618,22 +619,56 @@ namespace {
 // point at that row.
 int gemm(oake_handle* h, hipStream_t s, const char* name, int epi, const void* A, const void* W,
          const float* bias, void* out, int M, int N, int K, int ldo,
-         const float* rowstat = nullptr, const float* colsum = nullptr, size_t row0 = 0) {
+         const float* rowstat = nullptr, const float* colsum = nullptr, size_t row0 = 0,
+         int nparts_in = 0) {
   GemmArgs a{};
   a.A = A; a.W = W; a.bias = bias; a.out = out; a.M = M; a.N = N; a.K = K; a.ldo = ldo;
   a.rowstat = rowstat ? rowstat + row0 * 2 : nullptr;
   a.colsum = colsum;
-  // row statistics travel GEMM -> GEMM when the stream's shapes run the persistent kernel
+  a.opts = &h->opts;
+  // Which kernel runs is decided per call, from the shape actually passed (the persistent kernel takes
+  // LayerNorm statistics as per-row (sum, sum^2) slices, the small kernels as (rstd, -mean rstd)):
+  // ln_stats() prepared whichever this call needs and returned nparts_in.
+  const bool persistent = gemm_uses_persistent(M, N, K, &h->opts);
   float* part = h->rowpart + row0 * 32;
-  if (h->stat_fused && (epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN)) {
+  if ((epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) && persistent) {
+    if (nparts_in < 1) return fail(h, OAKE_ERR_STATE, std::string(name) + ": no row statistics for the persistent kernel");
     a.rowpart_in = part;
-    a.nparts = h->nparts;
+    a.nparts = nparts_in;
   }
+  // row statistics travel GEMM -> GEMM when the stream's shapes run the persistent kernel
   const char* xb = reinterpret_cast<const char*>(h->x);
   const bool to_resid = out == xb + row0 * (size_t)ldo * (h->xdt == DT_F32 ? 4 : 2);
-  if (h->stat_fused && epi == EPI_RESID16 && to_resid) a.rowpart_out = part;
+  if (h->stat_fused && epi == EPI_RESID16 && to_resid) {
+    if (!persistent)  // (stat_fused promises the next LN-folded GEMM a hand-over; only the persistent kernel writes one)
+      return fail(h, OAKE_ERR_STATE, std::string(name) + ": statistics hand-over needs the persistent kernel");
+    a.rowpart_out = part;
+  }
   RUNK(h, s, name, 2.0 * M * N * K, 0.0, launch_gemm(h->dt16, epi, a, s));
   if (a.rowpart_out) h->nparts = N / 64;
+  return OAKE_OK;
+}
+
+// LayerNorm statistics of residual rows [r0, r0 + M) (xr points at row r0) for the LN-folded GEMM
+// [M, N, K] that follows.  Returns through *nparts what gemm() needs: > 0 = the persistent kernel reads
+// that many (sum, sum^2) slices per row from rowpart — handed over by the kernel that wrote the rows
+// (stat_fused) or produced here by one rowsums pass (slot 0); 0 = a small kernel reads (rstd, -mean rstd)
+// from rowstat, produced here.
+int ln_stats(oake_handle* h, hipStream_t s, const char* xr, size_t r0, int M, int N, int K, int* nparts) {
+  if (gemm_uses_persistent(M, N, K, &h->opts)) {
+    if (h->stat_fused) {
+      *nparts = h->nparts;
+      return OAKE_OK;
+    }
+    RUN(h, s, "rowsums", 0.0, (double)M * K * 2,
+        launch_rowsums(xr, h->xdt, K, h->rowpart + r0 * 32, M, K, s));
+    *nparts = 1;
+    return OAKE_OK;
+  }
+  if (h->stat_fused)  // (cannot happen with the current kernel selection: stat_fused implies M > 1024)
+    return fail(h, OAKE_ERR_STATE, "statistics hand-over into a non-persistent GEMM");
+  RUN(h, s, "rowstat", 0.0, (double)M * K * 2, launch_rowstat(xr, h->xdt, K, h->rowstat + r0 * 2, M, K, s));
+  *nparts = 0;
   return OAKE_OK;
 }
 
@@ -648,6 +683,7 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   GemmArgs a{};
   a.A = h->a_patch; a.W = h->conv_w; a.bias = nullptr; a.out = h->x;
   a.M = nb * h->p2; a.N = C; a.K = h->kpatch; a.ldo = C; a.pos = h->pos; a.P2 = h->p2; a.L = L;
+  a.opts = &h->opts;
   RUNK(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0,
       launch_gemm(h->dt16, h->xdt == DT_F32 ? EPI_PATCH : EPI_PATCH16, a, s));
   // 16-bit residual stream + every main-stream GEMM on the persistent kernel: LayerNorm statistics
@@ -655,8 +691,8 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   const int T = nb * L;
   h->cur_len = L;
   h->stat_fused = h->xdt != DT_F32 && C % 64 == 0 && C / 64 <= 16 &&
-                  gemm_uses_persistent(T, C, C) && gemm_uses_persistent(T, C, c.mlp_dim) &&
-                  gemm_uses_persistent(T, 2 * C, C) && gemm_uses_persistent(T, c.mlp_dim, C);
+                  gemm_uses_persistent(T, C, C, &h->opts) && gemm_uses_persistent(T, C, c.mlp_dim, &h->opts) &&
+                  gemm_uses_persistent(T, 2 * C, C, &h->opts) && gemm_uses_persistent(T, c.mlp_dim, C, &h->opts);
   RUN(h, s, "embed_ln_pre", 0.0, 2.0 * nb * L * C * 4,
       launch_embed_ln_pre(h->x, h->xdt, h->cls, h->pos, h->lnpre_g, h->lnpre_b, nb, L, C,
                           h->stat_fused ? h->rowpart : nullptr, s));
@@ -681,12 +717,11 @@ int in_proj_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int 
     return gemm(h, s, name, EPI_T16_BIAS, xn, wp, w.in_b + n0, out, M, N, C, 3 * C);
   }
   // 16-bit residual stream: ln_1 folded into the GEMM, which reads the raw residual rows
-  if (!h->stat_fused)
-    RUN(h, s, "rowstat", 0.0, (double)M * C * 2,
-        launch_rowstat(xr, h->xdt, C, h->rowstat + r0 * 2, M, C, s));
+  int np = 0, rc;
+  if ((rc = ln_stats(h, s, xr, r0, M, N, C, &np))) return rc;
   const char* wp = reinterpret_cast<const char*>(w.in_wf) + (size_t)n0 * C * es;
   return gemm(h, s, name, EPI_T16_BIAS_LN, xr, wp, w.in_bf + n0, out, M, N, C, 3 * C, h->rowstat,
-              w.in_cs + n0, r0);
+              w.in_cs + n0, r0, np);
 }
 
 // attention out-proj (+residual) -> ln_2 + c_fc (+QuickGELU) -> c_proj (+residual) of rows [r0, r0 + M)
@@ -709,11 +744,10 @@ int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, c
     if ((rc = gemm(h, s, n_fc.c_str(), EPI_T16_GELU, xn, w.fc_w, w.fc_b, hb, M, F, C, F))) return rc;
   } else {
     // ln_2 folded into c_fc: the GEMM reads the raw residual rows
-    if (!h->stat_fused)
-      RUN(h, s, "rowstat", 0.0, (double)M * C * 2,
-          launch_rowstat(xr, h->xdt, C, h->rowstat + r0 * 2, M, C, s));
+    int np = 0;
+    if ((rc = ln_stats(h, s, xr, r0, M, F, C, &np))) return rc;
     if ((rc = gemm(h, s, n_fc.c_str(), EPI_T16_GELU_LN, xr, w.fc_wf, w.fc_bf, hb, M, F, C, F, h->rowstat,
-                   w.fc_cs, r0)))
+                   w.fc_cs, r0, np)))
       return rc;
   }
   return gemm(h, s, n_pr.c_str(), resid, hb, w.proj_w, w.proj_b, xr, M, C, F, C, nullptr, nullptr, r0);
@@ -728,7 +762,8 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   const int C = h->cfg.width, L = h->cur_len, T = nb * L;
   const int Lp = ((L + 63) / 64) * 64;
   RUNK(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
-      launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s));
+      launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s, nullptr, nullptr, 0,
+                       nullptr, &h->opts));
   return mlp_rows(h, s, w, 0, T, "");
 }
 
@@ -878,7 +913,7 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
     // as the objects stream's, through the same code: the CLS rows are copied
     // to rows T .. T+nb and attend over the patch rows + themselves (object_attention with a zero mask).
     // Identical results row for row; 6.7 % fewer FLOPs per image at 12 layers.
-    const bool cls_last = g_cls_last && L >= 2 && L <= 1024;
+    const bool cls_last = h->cls_last && L >= 2 && L <= 1024;
     const size_t xs = h->xdt == DT_F32 ? 4 : 2;
     char* yrows = reinterpret_cast<char*>(h->x) + (size_t)T * C * xs;
     for (int l = 0; l < c.layers; ++l) {
@@ -932,7 +967,9 @@ int oake_encode_text(oake_handle* h, const int32_t* d_tokens, int n, int length,
   const int C = c.width, L = length;
   const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
   // the workspace holds max_batch sequences of the full context; shorter sequences pack more per pass
-  const int per_pass = (int)std::min<long>(((long)c.max_batch * h->tokens) / L, 0x7fffffffL / (3L * C * L));
+  // ... but never more than the head buffers (gather_eot -> ln_final -> projection -> normalise) hold
+  const int per_pass = (int)std::min<long>(std::min<long>(((long)c.max_batch * h->tokens) / L, h->head_rows),
+                                           0x7fffffffL / (3L * C * L));
   for (int b0 = 0; b0 < n; b0 += per_pass) {
     const int nb = std::min(per_pass, n - b0);
     const int T = nb * L;
@@ -940,8 +977,8 @@ int oake_encode_text(oake_handle* h, const int32_t* d_tokens, int n, int length,
     char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
     h->cur_len = L;
     h->stat_fused = h->xdt != DT_F32 && C % 64 == 0 && C / 64 <= 16 &&
-                    gemm_uses_persistent(T, C, C) && gemm_uses_persistent(T, C, c.mlp_dim) &&
-                    gemm_uses_persistent(T, 3 * C, C) && gemm_uses_persistent(T, c.mlp_dim, C);
+                    gemm_uses_persistent(T, C, C, &h->opts) && gemm_uses_persistent(T, C, c.mlp_dim, &h->opts) &&
+                    gemm_uses_persistent(T, 3 * C, C, &h->opts) && gemm_uses_persistent(T, c.mlp_dim, C, &h->opts);
     // clip model.py encode_text: token_embedding(text) + positional_embedding[:L]
     RUN(h, s, "text_embed", 0.0, (double)T * C * 10,
         launch_text_embed(toks, h->tok_emb, h->pos, h->x, h->xdt, nb, L, C, h->vocab,
@@ -1022,7 +1059,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       }
       // object-token attention (Hooks.residual_attention_block_forward_pre, objects.py:223-247): on an
       // idle wave of the main stream's attention launch when there is one, else its own kernel
-      const bool fuse = !last && attention_fuses_object_token(L);
+      const bool fuse = !last && attention_fuses_object_token(L, &h->opts);
       if (!fuse)
         RUNK(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
             launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s));
@@ -1030,7 +1067,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
         const int Lp = ((L + 63) / 64) * 64;
         RUNK(h, s, "attention", 4.0 * nb * c.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
             launch_attention(h->dt16, h->qkv, h->att, nb, L, c.heads, 0, s, fuse ? qkv_y : nullptr,
-                             fuse ? masks : nullptr, mask_dtype, fuse ? att_y : nullptr));
+                             fuse ? masks : nullptr, mask_dtype, fuse ? att_y : nullptr, &h->opts));
         if ((rc = mlp_rows(h, s, w, 0, T + nb, ""))) return rc;
       } else {
         const bool fused = h->stat_fused;
@@ -1368,6 +1405,7 @@ int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bias, float
                     int k, int dtype16, void* stream) {
   GemmArgs a{};
   a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
+  a.opts = &t_debug_opts;
   return dbg(launch_gemm(dtype16, EPI_F32_BIAS, a, reinterpret_cast<hipStream_t>(stream)));
 }
 
@@ -1375,8 +1413,10 @@ int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, voi
                       int k, int dtype16, int gelu, void* stream) {
   GemmArgs a{};
   a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
-  return dbg(launch_gemm(dtype16, gelu ? EPI_T16_GELU : EPI_T16_BIAS, a,
-                         reinterpret_cast<hipStream_t>(stream)));
+  a.opts = &t_debug_opts;
+  // gelu: 0 bias, 1 bias + QuickGELU; measurement-only: 2 = no epilogue at all, 3 = pack + store only
+  const int epi = gelu == 1 ? EPI_T16_GELU : gelu == 2 ? EPI_T16_NONE : gelu == 3 ? EPI_T16_RAW : EPI_T16_BIAS;
+  return dbg(launch_gemm(dtype16, epi, a, reinterpret_cast<hipStream_t>(stream)));
 }
 
 int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gamma,
@@ -1398,6 +1438,7 @@ int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gam
     GemmArgs a{};
     a.A = d_x; a.W = wf; a.bias = bf; a.out = d_c; a.M = m; a.N = n; a.K = k; a.ldo = n;
     a.rowstat = stat; a.colsum = cs; a.rowpart_in = part; a.nparts = 1;
+    a.opts = &t_debug_opts;
     e = launch_gemm(dtype16, gelu ? EPI_T16_GELU_LN : EPI_T16_BIAS_LN, a, s);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1413,8 +1454,8 @@ int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, con
 
 int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads, int dtype16,
                          void* stream) {
-  return dbg(launch_attention(dtype16, d_qkv, d_out, n, l, heads, 0,
-                              reinterpret_cast<hipStream_t>(stream)));
+  return dbg(launch_attention(dtype16, d_qkv, d_out, n, l, heads, 0, reinterpret_cast<hipStream_t>(stream),
+                              nullptr, nullptr, 0, nullptr, &t_debug_opts));
 }
 
 int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
@@ -1422,7 +1463,7 @@ int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
 }
 
 int oake_debug_set_gemm_variant(int variant) {
-  oake::g_gemm_variant = variant < 0 ? -1 : variant;
+  t_debug_opts.gemm_variant = variant < 0 ? -1 : variant;
   return OAKE_OK;
 }
 
@@ -1430,32 +1471,84 @@ int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const float* d_bia
                             float* d_rowpart, int m, int n, int k, int dtype16, void* stream) {
   GemmArgs a{};
   a.A = d_a; a.W = d_w; a.bias = d_bias; a.out = d_x; a.M = m; a.N = n; a.K = k; a.ldo = n;
-  a.rowpart_out = gemm_uses_persistent(m, n, k) ? d_rowpart : nullptr;
+  a.opts = &t_debug_opts;
+  a.rowpart_out = gemm_uses_persistent(m, n, k, &t_debug_opts) ? d_rowpart : nullptr;
   return dbg(launch_gemm(dtype16, EPI_RESID16, a, reinterpret_cast<hipStream_t>(stream)));
 }
 
-int oake_debug_set_cls_last(int enable) {
-  g_cls_last = enable ? 1 : 0;
-  return OAKE_OK;
-}
-
 int oake_debug_set_gemm_panel(int panel) {
-  oake::g_gemm_panel = panel;
+  t_debug_opts.gemm_panel = panel;
   return OAKE_OK;
 }
 
 int oake_debug_set_gemm_trace(void* d_trace) {
-  oake::g_gemm_trace = reinterpret_cast<unsigned long long*>(d_trace);
+  t_debug_opts.gemm_trace = reinterpret_cast<unsigned long long*>(d_trace);
   return OAKE_OK;
 }
 
 int oake_debug_set_attention_variant(int variant) {
-  // bit 0: ds_read_b64_tr_b16 V fragments (else 16-bit gathers); bit 1: 32 queries per wave (else 64)
-  oake::g_attention_use_tr = (variant & 1) ? 1 : 0;
-  oake::g_attention_q32 = (variant & 2) ? 1 : 0;
-  oake::g_attention_coop = (variant & 4) ? 1 : 0;
-  oake::g_attention_fuse_obj = (variant & 8) ? 1 : 0;
-  oake::g_attention_pair = (variant & 16) ? 1 : 0;
+  t_debug_opts.attention_variant = variant & 31;
+  return OAKE_OK;
+}
+
+int oake_set_option(oake_handle* h, int option, int value) {
+  if (!h) return OAKE_ERR_INVALID;
+  switch (option) {
+    case OAKE_OPT_CLS_LAST: h->cls_last = value ? 1 : 0; return OAKE_OK;
+    case OAKE_OPT_GEMM_VARIANT: h->opts.gemm_variant = value < 0 ? -1 : value; return OAKE_OK;
+    case OAKE_OPT_GEMM_PANEL: h->opts.gemm_panel = value; return OAKE_OK;
+    case OAKE_OPT_ATTENTION_VARIANT: h->opts.attention_variant = value & 31; return OAKE_OK;
+    default: return fail(h, OAKE_ERR_INVALID, "unknown option " + std::to_string(option));
+  }
+}
+
+int oake_get_option(const oake_handle* h, int option, int* value) {
+  if (!h || !value) return OAKE_ERR_INVALID;
+  switch (option) {
+    case OAKE_OPT_CLS_LAST: *value = h->cls_last; return OAKE_OK;
+    case OAKE_OPT_GEMM_VARIANT: *value = h->opts.gemm_variant; return OAKE_OK;
+    case OAKE_OPT_GEMM_PANEL: *value = h->opts.gemm_panel; return OAKE_OK;
+    case OAKE_OPT_ATTENTION_VARIANT: *value = h->opts.attention_variant; return OAKE_OK;
+    default: return OAKE_ERR_INVALID;
+  }
+}
+
+// Test hook: a 16-bit matmul weight as it sits on the device (after the f32 -> 16-bit upload, the 1/8 scale
+// of the q rows, the transposition of the projection; "<key>#folded": the gamma-folded copy).
+int oake_debug_read_weight16(oake_handle* h, const char* name, uint16_t* h_out, size_t numel) {
+  if (!h || !name || !h_out) return OAKE_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = check_ready(h);
+  if (rc) return rc;
+  std::string key(name);
+  bool folded = false;
+  const size_t hash = key.find('#');
+  if (hash != std::string::npos) {
+    folded = key.substr(hash) == "#folded";
+    key = key.substr(0, hash);
+  }
+  const size_t C = h->cfg.width, F = h->cfg.mlp_dim, E = h->cfg.embed_dim;
+  const void* src = nullptr;
+  size_t n = 0;
+  if (!h->text && key == "visual.conv1.weight") { src = h->conv_w; n = C * h->kpatch; }
+  else if (key == (h->text ? "text_projection" : "visual.proj")) { src = h->proj; n = C * E; }
+  else {
+    const std::string prefix = h->text ? "transformer.resblocks." : "visual.transformer.resblocks.";
+    if (key.compare(0, prefix.size(), prefix) != 0) return fail(h, OAKE_ERR_UNKNOWN_TENSOR, "unknown tensor: " + key);
+    const size_t dot = key.find('.', prefix.size());
+    if (dot == std::string::npos) return fail(h, OAKE_ERR_UNKNOWN_TENSOR, "unknown tensor: " + key);
+    const int l = std::atoi(key.substr(prefix.size(), dot - prefix.size()).c_str());
+    if (l < 0 || l >= (int)h->layers.size()) return fail(h, OAKE_ERR_UNKNOWN_TENSOR, "unknown tensor: " + key);
+    const std::string leaf = key.substr(dot + 1);
+    const LayerW& w = h->layers[l];
+    if (leaf == "attn.in_proj_weight") { src = folded ? w.in_wf : w.in_w; n = 3 * C * C; }
+    else if (leaf == "attn.out_proj.weight" && !folded) { src = w.out_w; n = C * C; }
+    else if (leaf == "mlp.c_fc.weight") { src = folded ? w.fc_wf : w.fc_w; n = F * C; }
+    else if (leaf == "mlp.c_proj.weight" && !folded) { src = w.proj_w; n = C * F; }
+  }
+  if (!src) return fail(h, OAKE_ERR_UNKNOWN_TENSOR, "no 16-bit weight named " + std::string(name));
+  if (n != numel) return fail(h, OAKE_ERR_INVALID, key + ": expected " + std::to_string(n) + " elements");
+  HIP_TRY(h, hipMemcpy(h_out, src, n * 2, hipMemcpyDeviceToHost));
   return OAKE_OK;
 }
 

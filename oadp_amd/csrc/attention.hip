@@ -766,28 +766,31 @@ __global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* 
 
 }  // namespace
 
-// 0 = 16-bit LDS gathers for the V fragments, 1 = ds_read_b64_tr_b16 (set by api.hip)
-int g_attention_use_tr = 1;
-
-// 0 = 64 queries per wave, 1 = 32 queries per wave (half the registers, twice the waves)
-int g_attention_q32 = 1;
-
-// 1 = sequences longer than one key chunk share K / V through LDS (attention_coop_kernel)
-int g_attention_coop = 1;
-// 1 = objects mode: the object token's attention rides on an idle wave of that kernel
-int g_attention_fuse_obj = 1;
-// L <= 64 without a causal mask: two waves share an item's K / V in LDS (attention_pair_kernel)
-int g_attention_pair = 1;
+// LaunchOpts::attention_variant bits (default 31 = all set):
+//   1  ds_read_b64_tr_b16 V fragments (else 16-bit LDS gathers)
+//   2  32 queries per wave (else 64: twice the registers, half the waves)
+//   4  sequences longer than one key chunk share K / V through LDS (attention_coop_kernel)
+//   8  objects mode: the object token's attention rides on an idle wave of that kernel
+//  16  L <= 64 without a causal mask: two waves share an item's K / V in LDS (attention_pair_kernel)
+namespace {
+struct AttnBits {
+  bool use_tr, q32, coop, fuse_obj, pair;
+  explicit AttnBits(const LaunchOpts* o) {
+    const int v = o ? o->attention_variant : 31;
+    use_tr = v & 1; q32 = v & 2; coop = v & 4; fuse_obj = v & 8; pair = v & 16;
+  }
+};
+}  // namespace
 
 template <typename T, int MT>
 static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, int causal,
-                          hipStream_t s) {
+                          hipStream_t s, bool use_tr) {
   const int QB = (L + 16 * MT - 1) / (16 * MT);
   const int tw = n * heads * QB;
   const dim3 g((tw + 3) / 4), b(256);
   const T* in = reinterpret_cast<const T*>(qkv);
   T* o = reinterpret_cast<T*>(out);
-  if (g_attention_use_tr)
+  if (use_tr)
     OAKE_LAUNCH((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
   else
     OAKE_LAUNCH((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
@@ -810,21 +813,23 @@ static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, i
   return hipGetLastError();
 }
 
-bool attention_fuses_object_token(int L) {
+bool attention_fuses_object_token(int L, const LaunchOpts* opts) {
   // needs the cooperative kernel and a wave without queries in the last block of each head
+  const AttnBits b(opts);
   const int tail = L - 128 * ((L + 127) / 128 - 1);
-  return g_attention_coop && g_attention_use_tr && g_attention_fuse_obj && L > 64 && L <= 256 && tail <= 96;
+  return b.coop && b.use_tr && b.fuse_obj && L > 64 && L <= 256 && tail <= 96;
 }
 
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
                             int causal, hipStream_t s, const void* qkv_y, const void* mask,
-                            int mask_dtype, void* out_y) {
+                            int mask_dtype, void* out_y, const LaunchOpts* opts) {
   if (n <= 0) return hipSuccess;
-  if (qkv_y != nullptr && !attention_fuses_object_token(L)) return hipErrorInvalidValue;
+  const AttnBits bits(opts);
+  if (qkv_y != nullptr && !attention_fuses_object_token(L, opts)) return hipErrorInvalidValue;
   if (qkv_y != nullptr && mask_dtype != DT_F32 && mask_dtype != DT_F16) return hipErrorInvalidValue;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
-  if (g_attention_coop && g_attention_use_tr && L > 64) {
+  if (bits.coop && bits.use_tr && L > 64) {
     const int QG = (L + 127) / 128;
     const dim3 grid(n * heads * QG), blk(256);
     const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
@@ -838,17 +843,17 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
       return hipErrorInvalidValue;
     return hipGetLastError();
   }
-  if (g_attention_pair && g_attention_use_tr && L <= 64 && !causal && qkv_y == nullptr) {
+  if (bits.pair && bits.use_tr && L <= 64 && !causal && qkv_y == nullptr) {
     if (dtype16 == DT_F16) return attn_pair_launch_t<f16_t>(qkv, out, n, L, heads, s);
     if (dtype16 == DT_BF16) return attn_pair_launch_t<bf16_t>(qkv, out, n, L, heads, s);
     return hipErrorInvalidValue;
   }
   if (dtype16 == DT_F16) {
-    if (g_attention_q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, causal, s);
-    else attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, causal, s);
+    if (bits.q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, causal, s, bits.use_tr);
+    else attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, causal, s, bits.use_tr);
   } else if (dtype16 == DT_BF16) {
-    if (g_attention_q32) attn_launch_t<bf16_t, 2>(qkv, out, n, L, heads, causal, s);
-    else attn_launch_t<bf16_t, 4>(qkv, out, n, L, heads, causal, s);
+    if (bits.q32) attn_launch_t<bf16_t, 2>(qkv, out, n, L, heads, causal, s, bits.use_tr);
+    else attn_launch_t<bf16_t, 4>(qkv, out, n, L, heads, causal, s, bits.use_tr);
   } else {
     return hipErrorInvalidValue;
   }

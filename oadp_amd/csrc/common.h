@@ -10,9 +10,9 @@ namespace oake {
 // Kernel-level timing for the profiler (api.hip, RUNK): when the two events are set, a launch made
 // through OAKE_LAUNCH stamps them with the kernel's own begin / end (hipExtLaunchKernelGGL) — the
 // same interval rocprofv3's kernel trace reports.  Bracketing a launch with hipEventRecord instead
-// includes ~5 us of dispatch latency per kernel.  Null events: a plain launch.  (Process-wide: one
-// handle profiles at a time.)
-extern hipEvent_t g_launch_start, g_launch_stop;
+// includes ~5 us of dispatch latency per kernel.  Null events: a plain launch.  (Per host thread: set
+// around one launch by the thread that makes it.)
+extern thread_local hipEvent_t g_launch_start, g_launch_stop;
 #define OAKE_LAUNCH(kern, grid, block, lds, stream, ...)                                         \
   hipExtLaunchKernelGGL(kern, grid, block, lds, stream, oake::g_launch_start, oake::g_launch_stop, 0, \
                         __VA_ARGS__)

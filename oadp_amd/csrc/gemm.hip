@@ -36,11 +36,6 @@
 
 namespace oake {
 
-int g_gemm_panel = 0;     // debug: 0 = default tile order, n > 0: N panels of n tiles, n < 0: M slabs of -n tiles
-int g_gemm_variant = -1;  // -1 = auto (per-shape), else forced configuration (tests / A-B runs)
-// debug: per-tile s_memtime stamps of gemm_pp_kernel's compute wave 0 / 4 (tools/gemm_trace.py)
-unsigned long long* g_gemm_trace = nullptr;
-
 namespace {
 
 constexpr int BK = 64;
@@ -81,8 +76,10 @@ struct EpiTraits {
   static constexpr bool kLn = (EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN);
   static constexpr bool kGelu = (EPI == EPI_T16_GELU || EPI == EPI_T16_GELU_LN);
   // pure stores (no read-modify-write): the persistent kernel may hold them back and trickle them
-  static constexpr bool kTrickle = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || kLn);
-  static constexpr bool kPaired = (kTrickle || EPI == EPI_RESID16 || EPI == EPI_PATCH16);
+  static constexpr bool kNone = (EPI == EPI_T16_NONE);   // measurement: no epilogue at all
+  static constexpr bool kRaw = (EPI == EPI_T16_RAW);     // measurement: pack + store only
+  static constexpr bool kTrickle = (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || kLn || kRaw);
+  static constexpr bool kPaired = (kTrickle || EPI == EPI_RESID16 || EPI == EPI_PATCH16 || kNone);
 };
 
 // acc -> acc + bias, or the folded LayerNorm  rstd * acc + (-mean rstd) * colsum + bias
@@ -172,6 +169,13 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
                                                    int M, int N, const EpiParams& ep, bool reset,
                                                    const char* elds, int lcol, int lrow) {
   constexpr bool PAIRED = EpiTraits<EPI>::kPaired;
+  if constexpr (EpiTraits<EPI>::kNone) {  // measurement: the MFMAs stay live, nothing is computed or stored
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+    return;
+  }
   if (PAIRED) {
     static_assert(!PAIRED || NI % 2 == 0, "paired mapping needs an even number of column tiles");
     constexpr int NP = NI / 2;
@@ -393,7 +397,7 @@ __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&p
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
     const int lc = lcol + 32 * t;
-    const bool ok = ep.bias != nullptr;
+    const bool ok = ep.bias != nullptr && !EpiTraits<EPI>::kRaw;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 b0 = ok ? epi_vec4<true>(nullptr, 0, elds, EpiLds::kBias, lc) : z4;
     const float4 b1 = ok ? epi_vec4<true>(nullptr, 0, elds, EpiLds::kBias, lc + 4) : z4;
@@ -409,10 +413,12 @@ __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&p
         const f32x2 rv = *(lds_f2_t)(elds + EpiLds::kRowstat + (lrow + mi * 16) * 8);
         r = make_float2(rv[0], rv[1]);
       }
-      lo[0] = epi_affine<LN>(lo[0], b0.x, cl.x, r); lo[1] = epi_affine<LN>(lo[1], b0.y, cl.y, r);
-      lo[2] = epi_affine<LN>(lo[2], b0.z, cl.z, r); lo[3] = epi_affine<LN>(lo[3], b0.w, cl.w, r);
-      hi[0] = epi_affine<LN>(hi[0], b1.x, ch.x, r); hi[1] = epi_affine<LN>(hi[1], b1.y, ch.y, r);
-      hi[2] = epi_affine<LN>(hi[2], b1.z, ch.z, r); hi[3] = epi_affine<LN>(hi[3], b1.w, ch.w, r);
+      if constexpr (!EpiTraits<EPI>::kRaw) {
+        lo[0] = epi_affine<LN>(lo[0], b0.x, cl.x, r); lo[1] = epi_affine<LN>(lo[1], b0.y, cl.y, r);
+        lo[2] = epi_affine<LN>(lo[2], b0.z, cl.z, r); lo[3] = epi_affine<LN>(lo[3], b0.w, cl.w, r);
+        hi[0] = epi_affine<LN>(hi[0], b1.x, ch.x, r); hi[1] = epi_affine<LN>(hi[1], b1.y, ch.y, r);
+        hi[2] = epi_affine<LN>(hi[2], b1.z, ch.z, r); hi[3] = epi_affine<LN>(hi[3], b1.w, ch.w, r);
+      }
       if (EpiTraits<EPI>::kGelu) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -1177,14 +1183,15 @@ TileMap make_tilemap(const GemmArgs& a, int BM, int BN) {
   int pn = 768 / BN;  // ~768-column panels: a W panel of K=768 is ~1.2 MB of an XCD's 4 MiB L2
   pn = pn < 1 ? 1 : pn;
   tmap.by_m = 0;
-  if (g_gemm_panel > 0) pn = g_gemm_panel;
-  if (g_gemm_panel < 0) {
+  const int panel = a.opts ? a.opts->gemm_panel : 0;
+  if (panel > 0) pn = panel;
+  if (panel < 0) {
     tmap.by_m = 1;
-    pn = -g_gemm_panel;
+    pn = -panel;
   }
   const int outer = tmap.by_m ? tmap.tiles_m : tmap.tiles_n;
   tmap.pn = pn > outer ? outer : pn;
-  tmap.trace = g_gemm_trace;
+  tmap.trace = a.opts ? a.opts->gemm_trace : nullptr;  // per-tile s_memtime stamps (tools/gemm_trace.py)
   return tmap;
 }
 
@@ -1296,6 +1303,10 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
 //                  7: one compute wave per SIMD, 160x256, one tile per block (gemm_q4_kernel; experiment)
 template <typename T, int EPI>
 hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
+  if constexpr (EpiTraits<EPI>::kNone || EpiTraits<EPI>::kRaw) {  // measurement epilogues: persistent kernels only
+    if (variant == 8) return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);
+    return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
+  } else
   switch (variant) {
     case 0: return launch_simple<T, EPI, 128, 128, 2, 2>(a, s);
     case 1: return launch_simple<T, EPI, 160, 256, 2, 4>(a, s);
@@ -1304,6 +1315,7 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 4: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     case 5: return launch_deep<T, EPI, 64, 64, 2, 2>(a, s);
     case 6: return launch_simple<T, EPI, 64, 64, 2, 2>(a, s);
+    case 8: return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);  // experiment: 64 x 64 wave tiles
     case 7:  // one compute wave per SIMD (experiment): residual / bias epilogues without LN statistics from LDS
       if constexpr (EPI == EPI_RESID16 || EPI == EPI_T16_BIAS || EPI == EPI_F32_BIAS)
         return launch_q4<T, EPI, 160, 256>(a, s);
@@ -1314,7 +1326,7 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
 }
 
 int pick_variant(const GemmArgs& a) {
-  if (g_gemm_variant >= 0) return g_gemm_variant;
+  if (a.opts && a.opts->gemm_variant >= 0) return a.opts->gemm_variant;
   // few-hundred-row problems: 64x64 tiles spread over the CUs, deep ring against the per-K-tile latency
   if ((long)a.M * a.N <= 512 * 1024 || a.M <= 1024) return 5;
   if (a.N < 256) return 0;
@@ -1334,28 +1346,32 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_PATCH16: return launch_variant<T, EPI_PATCH16>(v, a, s);
     case EPI_T16_BIAS_LN: return launch_variant<T, EPI_T16_BIAS_LN>(v, a, s);
     case EPI_T16_GELU_LN: return launch_variant<T, EPI_T16_GELU_LN>(v, a, s);
+    case EPI_T16_NONE: return launch_variant<T, EPI_T16_NONE>(v, a, s);
+    case EPI_T16_RAW: return launch_variant<T, EPI_T16_RAW>(v, a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 }  // namespace
 
-bool gemm_uses_persistent(int M, int N, int K) {
+bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts) {
   GemmArgs a{};
   a.M = M; a.N = N; a.K = K;
-  return pick_variant(a) == 4 && K >= 3 * BK;
+  a.opts = opts;
+  const int v = pick_variant(a);
+  return (v == 4 || v == 8) && K >= 3 * BK;
 }
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
   if (a.K % BK != 0 || a.N % 4 != 0 || a.ldo % 4 != 0) return hipErrorInvalidValue;
   if ((epi == EPI_T16_BIAS || epi == EPI_T16_GELU || epi == EPI_RESID16 || epi == EPI_PATCH16 ||
-       epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) &&
+       epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN || epi == EPI_T16_NONE || epi == EPI_T16_RAW) &&
       (a.N % 8 != 0 || a.ldo % 8 != 0))
     return hipErrorInvalidValue;
   if (epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN) {
     if (a.colsum == nullptr || a.bias == nullptr) return hipErrorInvalidValue;
-    if (gemm_uses_persistent(a.M, a.N, a.K)
+    if (gemm_uses_persistent(a.M, a.N, a.K, a.opts)
             ? (a.rowpart_in == nullptr || a.nparts < 1 || a.nparts > kRowParts)
             : a.rowstat == nullptr)
       return hipErrorInvalidValue;

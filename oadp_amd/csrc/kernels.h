@@ -22,7 +22,19 @@ enum GemmEpi {
   // LayerNorm folded in (rowops.hip, fold_ln_kernel): W carries gamma, `bias` is b + W beta, and
   // out = rowstat[m].x * acc + rowstat[m].y * colsum[n] + bias[n]   (then QuickGELU for _GELU_LN)
   EPI_T16_BIAS_LN = 7,
-  EPI_T16_GELU_LN = 8
+  EPI_T16_GELU_LN = 8,
+  // measurement-only epilogues (tools/gemm_ablate.py): what a tile costs without its epilogue
+  EPI_T16_NONE = 9,   // nothing is stored (accumulators kept alive, then zeroed)
+  EPI_T16_RAW = 10    // out T16 = acc (no bias, no activation): the pack + store cost alone
+};
+
+// Kernel-selection switches of one caller (a handle, or the calling thread's handle-less oake_debug_* entry
+// points).  No process-wide state: two handles / lanes never see each other's settings.
+struct LaunchOpts {
+  int gemm_variant = -1;   // -1 = automatic per shape, else a forced tile configuration (csrc/gemm.hip)
+  int gemm_panel = 0;      // tile order: 0 default, n > 0 N panels of n tiles, n < 0 M slabs of -n tiles
+  unsigned long long* gemm_trace = nullptr;  // device buffer for per-tile cycle stamps, or nullptr
+  int attention_variant = 31;                // bits: see oake_debug_set_attention_variant
 };
 
 struct GemmArgs {
@@ -46,11 +58,12 @@ struct GemmArgs {
   float* rowpart_out;
   const float* rowpart_in;
   int nparts;
+  const LaunchOpts* opts;  // nullptr = defaults
 };
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
 // true when launch_gemm runs this shape on the persistent kernel (row statistics via rowpart_*)
-bool gemm_uses_persistent(int M, int N, int K);
+bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts = nullptr);
 
 // ---- row kernels -------------------------------------------------------------------------
 // y(16-bit)[rows,c] = LN(x [rows, c]); x is fp32 (x_dtype DT_F32) or the 16-bit type (x_dtype ==
@@ -96,8 +109,9 @@ hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, 
 // attention (launch_object_attention's job) done by the same launch.
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
                             int causal, hipStream_t s, const void* qkv_y = nullptr,
-                            const void* mask = nullptr, int mask_dtype = 0, void* out_y = nullptr);
-bool attention_fuses_object_token(int L);
+                            const void* mask = nullptr, int mask_dtype = 0, void* out_y = nullptr,
+                            const LaunchOpts* opts = nullptr);
+bool attention_fuses_object_token(int L, const LaunchOpts* opts = nullptr);
 
 // Object-token attention (oadp/oake/objects.py:232-247): one query per crop (qkv_y row n),
 // keys/values = patch rows 1..L-1 of qkv_x plus the object token's own k/v (qkv_y);

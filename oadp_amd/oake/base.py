@@ -83,6 +83,8 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
     def __init__(self, root: str, annFile: str, *, auto_fix: bool = False, output_dir: str,
                  transform=None, device_preprocess: bool = False,
                  device_decode: bool | str = False, **kwargs) -> None:
+        if kwargs:  # a misspelled option must not vanish silently
+            raise TypeError(f'{type(self).__name__}: unknown dataset option(s) {sorted(kwargs)}')
         self.coco = CocoImages(root, annFile)
         self.root = root
         self.ids = self.coco.ids
@@ -279,6 +281,8 @@ class BaseValidator(ABC, Generic[T]):
                  batch_size: int = 256, device: torch.device | str | None = None,
                  writer_threads: int = 4, decode_threads: int = 16, prefetch: int = 512,
                  streams: int = 2, **kwargs) -> None:
+        if kwargs:  # a misspelled option must not vanish silently
+            raise TypeError(f'{type(self).__name__}: unknown option(s) {sorted(kwargs)}')
         self.name = name
         self._model = model
         self._log_interval = (log or {}).get('interval', 50)
@@ -491,6 +495,10 @@ class BaseValidator(ABC, Generic[T]):
             torch.cuda.set_device(get_local_rank() % torch.cuda.device_count())
         if distributed:
             torch.distributed.init_process_group(backend='nccl' if Store.CUDA else 'gloo')
+
+        # the unpinned behaviours of the un-vendored fork (oadp_amd/clip/settings.py), before the model exists
+        from ..clip import settings as fork_settings
+        fork_settings.configure(**config.pop('fork', {}))
 
         model, preprocess = cls._build_model()
 

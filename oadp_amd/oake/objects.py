@@ -42,8 +42,12 @@ class ExpandMode(enum.Enum):
 
 
 def indices_min_wh(boxes: torch.Tensor, min_wh: tuple[float, float]) -> torch.Tensor:
+    """``todd.BBoxes.indices(min_wh=...)``: >= by default, > with ``fork.min_wh_inclusive = False``
+    (unknown upstream: oadp_amd/clip/settings.py)."""
     wh = boxes[:, 2:] - boxes[:, :2]
-    return (wh[:, 0] >= min_wh[0]) & (wh[:, 1] >= min_wh[1])
+    if clip.settings.min_wh_inclusive:
+        return (wh[:, 0] >= min_wh[0]) & (wh[:, 1] >= min_wh[1])
+    return (wh[:, 0] > min_wh[0]) & (wh[:, 1] > min_wh[1])
 
 
 class COCODataset(BaseDataset[Batch]):

@@ -102,3 +102,33 @@ class OracleModel:
 
 def preprocess():
     return Preprocess(224, squash=False)
+
+
+def tiny_state_dict(**arch):
+    """A small random-init vision state dict, stored the way OpenAI's ViT-B-32.pt stores its tensors:
+    matmul / conv weights and the projection in fp16, LayerNorm parameters and embeddings in fp32."""
+    sd = synthetic_state_dict(**arch)
+    half = ('conv1.weight', 'in_proj_weight', 'in_proj_bias', 'out_proj.weight', 'out_proj.bias',
+            'c_fc.weight', 'c_fc.bias', 'c_proj.weight', 'c_proj.bias', 'visual.proj')
+    return {k: (v.half() if k.endswith(half) else v) for k, v in sd.items()}
+
+
+def save_torchscript_checkpoint(sd, path) -> None:
+    """``sd`` as a TorchScript archive whose ``torch.jit.load(path).state_dict()`` returns it — the
+    container format of the reference's pretrained/clip/ViT-B-32.pt (README.md:129).  Includes the three
+    scalar entries OpenAI's archives carry next to the weights."""
+    import torch.nn as nn
+    root = nn.Module()
+    entries = dict(sd, input_resolution=torch.tensor(224), context_length=torch.tensor(77),
+                   vocab_size=torch.tensor(49408))
+    for key, value in entries.items():
+        parts, m = key.split('.'), root
+        for part in parts[:-1]:
+            if part not in m._modules:
+                m.add_module(part, nn.Module())
+            m = m._modules[part]
+        if value.is_floating_point():
+            m.register_parameter(parts[-1], nn.Parameter(value.clone(), requires_grad=False))
+        else:
+            m.register_buffer(parts[-1], value.clone())
+    torch.jit.save(torch.jit.script(root), str(path))

@@ -1,0 +1,61 @@
+"""bench.py's launcher contract: `python bench.py --gpus N` really runs N ranks
+(reference: torchrun --nproc_per_node=${GPUS}, README.md:197-207; oadp/oake/base.py:122-126)."""
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def _run(args, env_extra, timeout=600):
+    env = dict(os.environ, PYTHONPATH=str(ROOT), **env_extra)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *args], capture_output=True, text=True,
+                       env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_that_many_ranks_cpu_plumbing():
+    """No GPU here: the plumbing mode skips every GPU call but runs the real launcher, rendezvous,
+    barrier, max-over-ranks reduction and counters gather over gloo."""
+    line = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--no-profile'],
+                dict(OAKE_BENCH_DRY_PLUMBING='1'))
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
+    assert 'ranks gathered: 2' in line['config']['sharding']
+    assert line['value'] is None and 'dry-run' in line['data']  # carries no throughput claim
+    assert line['cpu_baseline'] is None
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, PYTHONPATH=str(ROOT), OAKE_BENCH_DRY_PLUMBING='1', WORLD_SIZE='1', RANK='0')
+    r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '1', '--no-profile'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_gpus_2_on_one_gpu_over_gloo():
+    """Two ranks sharing the one GPU of the test box (gloo instead of RCCL): the N > 1 path end to end."""
+    line = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--no-profile', '--no-cpu-baseline', '--batch', '32'],
+                dict(OAKE_BENCH_BACKEND='gloo'))
+    assert line['n_gpus'] == 2 and line['value'] > 0
+    assert 'ranks gathered: 2' in line['config']['sharding']
+    assert abs(line['crops_per_sec'] - line['value']) < 1e-6 * line['value'] + 1  # globals: one crop per image
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode,extra', [('blocks', ['--batch', '4']), ('objects', ['--batch', '2', '--proposals', '40'])])
+def test_modes_produce_a_contract_line(mode, extra):
+    line = _run(['--mode', mode, '--steps', '2', '--warmup', '1', '--no-cpu-baseline', *extra], {})
+    assert line['config']['mode'] == mode and line['n_gpus'] == 1 and line['value'] > 0
+    assert line['unit'] == 'images/sec' and line['crops_per_sec'] > line['value']
+    rf = line['roofline']
+    assert rf['bound'] == 'mfma' and 0 < rf['frac'] < 1 and rf['kernel'].startswith('gemm')

@@ -198,17 +198,16 @@ def test_last_block_for_cls_rows_only_is_exact_elimination(cuda, cfg, n, resid32
     """encode_image runs the last block's query / attention output / out_proj / MLP for the CLS rows only
     (ln_post reads nothing else).  Against the all-rows execution the reference performs: the same
     embeddings up to the rounding of different tile shapes, and both within tolerance of the oracle."""
-    from oadp_amd import _lib
-    lib = _lib.load()
     sd = synthetic_state_dict(**cfg) if cfg else synthetic_state_dict()
     model, _ = clip.load(sd, max_batch=64, residual_dtype=torch.float32 if resid32 else None)
     x = synthetic_images(n, seed=3).to(cuda)
-    try:
-        lib.oake_debug_set_cls_last(0)
-        full = model.encode_image(x, normalize=True, out_dtype=torch.float32)
-    finally:
-        lib.oake_debug_set_cls_last(1)
-    cls = model.encode_image(x, normalize=True, out_dtype=torch.float32)
+    # a per-handle switch (oake_set_option): a second model in the same process keeps its default
+    other, _ = clip.load(sd, max_batch=64, residual_dtype=torch.float32 if resid32 else None)
+    model.visual.set_option('cls_last', 0)
+    full = model.encode_image(x, normalize=True, out_dtype=torch.float32)
+    cls = other.encode_image(x, normalize=True, out_dtype=torch.float32)
+    model.visual.set_option('cls_last', 1)
+    assert torch.equal(model.encode_image(x, normalize=True, out_dtype=torch.float32), cls)
     cos = torch.nn.functional.cosine_similarity(full, cls, dim=1)
     print(f'max|cls - full|={(full - cls).abs().max().item():.3e} min cos={cos.min().item():.7f}')
     assert cos.min().item() > 0.99999
@@ -216,6 +215,25 @@ def test_last_block_for_cls_rows_only_is_exact_elimination(cuda, cfg, n, resid32
     ref = l2_normalize(encode_image_ref(sd, ViTConfig(**cfg) if cfg else ViTConfig(), x.cpu()))
     _check(cls, ref, 1e-3, 1e-3)
     _check(full, ref, 1e-3, 1e-3)
+
+
+def test_batches_beyond_1024_crops_per_pass(cuda):
+    """max_batch > 1024: the CLS rows of the last block (M = crops per pass) are then large enough for the
+    persistent GEMM, which takes its LayerNorm statistics as per-row sums — decided per GEMM from the shape
+    it is actually called with, not once per pass.  Same features as 256-crop passes."""
+    arch = dict(width=768, layers=2, heads=12, mlp_dim=3072, embed_dim=512)  # ViT-B/32 widths, 2 layers
+    sd = synthetic_state_dict(**arch)
+    x = synthetic_images(100, seed=9).half().repeat(11, 1, 1, 1).to(cuda)  # 1100 crops, 100 distinct
+    big, _ = clip.load(sd, max_batch=1100)
+    small, _ = clip.load(sd, max_batch=256)
+    a = big.encode_image(x, normalize=True, out_dtype=torch.float32)
+    b = small.encode_image(x, normalize=True, out_dtype=torch.float32)
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
+    print(f'max|a-b|={(a - b).abs().max().item():.3e} min cos={cos.min().item():.7f}')
+    assert cos.min().item() > 0.99999
+    torch.testing.assert_close(a, b, rtol=1e-3, atol=6e-4)
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(**arch), x[:6].float().cpu()))
+    _check(a[:6], ref, 1e-3, 1e-3)
 
 
 def test_lanes_are_independent_handles_on_their_own_streams(cuda):

@@ -1,0 +1,130 @@
+"""BASELINE.json configs[2] and [3] at their real sizes through the product pipeline on the GPU:
+full ViT-B/32 weights (12 layers, 87.8 M parameters), device preprocessing on.
+
+  blocks   one 1700x1134 image (all 5 pyramid levels, 245 crops) + one 640x480 image (27 crops) through
+           ``blocks.Validator`` -> .pth; bboxes bit-exact against the reference's own ``_preprocess``
+           output (tests/golden/blocks_partition.json), embeddings of a row subset against the oracle
+           (PIL pyramid + crops -> fp32 CPU encoder).
+  objects  one 640x480 image with 300 proposals (SURVEY.md §8d distribution) through ``objects.Validator``
+           (mini-batch 512) -> .pth; bboxes / objectness / masks bit-exact against the reference's own
+           ``_expand`` / ``_mask`` / ``_preprocess`` (tests/golden/objects_300.npz), embeddings of a row
+           subset against the oracle's dual-stream restatement of the reference's Hooks.
+
+Tolerance: BASELINE.json north_star — fp16 rtol 1e-3 / atol 1e-3 (+ the fp16 storage rounding of the
+saved file, <= 2.5e-4 on unit-norm features), cosine >= 0.999.
+"""
+import json
+import pathlib
+import pickle
+
+import numpy as np
+import PIL.Image
+import pytest
+import torch
+
+from oadp_amd import clip
+from oadp_amd.config import Config
+from oadp_amd.oake import blocks, objects
+from oadp_amd.weights import synthetic_state_dict
+from oracle.vit_ref import ViTConfig, encode_image_ref, encode_objects_ref, l2_normalize
+
+from . import _synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = pathlib.Path(__file__).parent / 'golden'
+
+
+def _close(got: torch.Tensor, ref: torch.Tensor) -> None:
+    got, ref = got.float(), ref.float()
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=1)
+    print(f'max|err|={(got - ref).abs().max().item():.3e} min cos={cos.min().item():.6f} rows={got.shape[0]}')
+    assert cos.min().item() >= 0.999
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1.25e-3)
+
+
+@pytest.fixture(scope='module')
+def vit_b32():
+    return synthetic_state_dict()
+
+
+def test_blocks_validator_full_size(cuda, tmp_path, vit_b32, monkeypatch):
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    coco = _synth.make_coco(tmp_path / 'coco', [(1700, 1134), (640, 480)])
+    sizes = {im['id']: (im['width'], im['height'], im['file_name'])
+             for im in json.loads(pathlib.Path(coco['annFile']).read_text())['images']}
+    golden = {tuple(g['size']): g for g in json.loads((GOLDEN / 'blocks_partition.json').read_text())['images']}
+    model, pre = clip.load(vit_b32, max_batch=512)
+    out = tmp_path / 'blocks'
+    dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(out), transform=pre,
+                             device_preprocess=True), num_workers=0)
+    v = blocks.Validator('blocks', model, dataloader=dl, device='cuda:0', batch_size=512)
+    v.run()
+    assert v.counters.images == 2 and v.counters.crops == 245 + 27
+    host_ds = blocks.Dataset(coco['root'], coco['annFile'], output_dir=str(tmp_path / 'unused'), transform=pre)
+    for id_, (w, h, name) in sizes.items():
+        got = torch.load(out / f'{id_:012d}.pth', 'cpu')
+        g = golden[(w, h)]
+        assert got['embeddings'].dtype == torch.float16 and got['bboxes'].dtype == torch.float16
+        assert got['embeddings'].shape == (g['n_blocks'], 512)
+        # crop indices: bit-exact with what the reference's _preprocess returned for this image size
+        assert torch.equal(got['bboxes'], torch.tensor(g['batch_bboxes']).half())
+        levels = sorted({round(t[2], 6) for t in g['tiles']})
+        assert len(levels) == (5 if (w, h) == (1700, 1134) else 2)
+        # embeddings: first / last block of every pyramid level + block 0, against the oracle
+        scale_of = [None] + [round(t[2], 6) for t in g['tiles']]
+        rows = {0}
+        for s in levels:
+            idx = [i for i, sc in enumerate(scale_of) if sc == s]
+            rows.update((idx[0], idx[-1], idx[len(idx) // 2]))
+        rows = sorted(rows)
+        host = host_ds._preprocess(id_, pathlib.Path('x'), PIL.Image.open(pathlib.Path(coco['root']) / name).convert('RGB'))
+        assert host.blocks.shape[0] == g['n_blocks']
+        ref = l2_normalize(encode_image_ref(vit_b32, ViTConfig(), host.blocks[rows]))
+        _close(got['embeddings'][rows], ref)
+        norms = got['embeddings'].float().norm(dim=1)
+        assert (norms - 1).abs().max().item() < 2e-3
+
+
+def test_objects_validator_full_size(cuda, tmp_path, vit_b32, monkeypatch):
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    gold = np.load(GOLDEN / 'objects_300.npz')
+    w, h = (int(v) for v in gold['image_size'])
+    coco = _synth.make_coco(tmp_path / 'coco', [(w, h)])
+    with open(coco['proposal_file'], 'wb') as f:
+        pickle.dump([gold['proposals']], f)
+    model, pre = clip.load(vit_b32, max_batch=512)
+    vis = model.visual  # the reference's surgery (oadp/oake/objects.py:292-301) + the object stream
+    vis.positional_embedding = vis.interpolate_positional_embedding((vis.grid * 2,) * 2)
+    vis.grid *= 2
+    vis.conv1.stride = tuple(s // 2 for s in vis.conv1.stride)
+    vis.conv1.padding = ((vis.patch_size - 1) // 2,) * 2
+    vis.object_stream = True
+    out = tmp_path / 'objects'
+    ds_cfg = dict(type='COCODataset', root=coco['root'], annFile=coco['annFile'], output_dir=str(out),
+                  transform=pre, proposal_file=coco['proposal_file'], proposal_sorted=True)
+    v = objects.Validator('objects', model, dataloader=Config(dataset=dict(ds_cfg, device_preprocess=True),
+                                                              num_workers=0),
+                          device='cuda:0', mini_batch_size=512, batch_size=512)
+    v.run()
+    n = int(gold['n_objects'])
+    assert n == 300 and v.counters.images == 1 and v.counters.crops == n
+    id_ = coco['ids'][0]
+    got = torch.load(out / f'{id_:012d}.pth', 'cpu')
+    assert got['embeddings'].shape == (n, 512) and got['embeddings'].dtype == torch.float16
+    # index math: bit-exact with the reference's own functions
+    assert torch.equal(got['bboxes'], torch.from_numpy(gold['bboxes']).half())
+    assert torch.equal(got['objectness'], torch.from_numpy(gold['objectness']).half())
+    host_ds = objects.COCODataset(coco['root'], coco['annFile'], output_dir=str(tmp_path / 'unused'),
+                                  transform=pre, grid=14, proposal_file=coco['proposal_file'], proposal_sorted=True)
+    name = json.loads(pathlib.Path(coco['annFile']).read_text())['images'][0]['file_name']
+    host = host_ds._preprocess(id_, pathlib.Path('x'), PIL.Image.open(pathlib.Path(coco['root']) / name).convert('RGB'))
+    assert torch.equal(host.masks.reshape(-1, 14, 14).to(torch.uint8), torch.from_numpy(gold['masks']))
+    prop = torch.from_numpy(gold['proposals'][:, :4])[torch.from_numpy(gold['keep'])]
+    assert torch.equal(host_ds._expand(prop, torch.tensor([w, h])), torch.from_numpy(gold['expanded']))
+    # embeddings of a row subset against the oracle (PIL crops, fp32 dual-stream encoder)
+    rows = [0, 1, 57, 149, 150, 298, 299]
+    sd = dict(vit_b32)
+    sd['visual.positional_embedding'] = vis.positional_embedding
+    ref = l2_normalize(encode_objects_ref(sd, ViTConfig(stride=16, padding=15), host.objects[rows], host.masks[rows]))
+    _close(got['embeddings'][rows], ref)
+    assert (got['embeddings'].float().norm(dim=1) - 1).abs().max().item() < 2e-3

@@ -20,9 +20,11 @@ def _check(out, ref, tol):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize('n,length', [(1, 24), (7, 24), (5, 9), (70, 24)])
+@pytest.mark.parametrize('n,length', [(1, 24), (7, 24), (5, 9), (70, 24), (300, 9)])
 def test_encode_text_tiny(cuda, dtype, tol, n, length):
-    """Small and large batches (70 x 24 = 1680 rows run the persistent GEMMs), trimmed contexts."""
+    """Small and large batches (70 x 24 = 1680 rows run the persistent GEMMs), trimmed contexts;
+    (300, 9): more sequences than max_batch AND a trimmed context, so one pass packs 85 > max_batch = 32
+    sequences — the head buffers (gather_eot -> ln_final -> projection) must hold them all."""
     sd = synthetic_text_state_dict(**TINY)
     model, _ = clip.load(sd, compute_dtype=dtype, max_batch=32)  # 70 > max_batch: multi-pass
     tok = synthetic_tokens(n, length, TINY['vocab'], seed=n)

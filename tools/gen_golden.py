@@ -351,6 +351,36 @@ def gen_objects(objects_mod):
     print('objects:', len(masks), 'mask cases;', [e['n_objects'] for e in expand], 'objects per image')
 
 
+def gen_objects_300(objects_mod):
+    """BASELINE.json configs[3] at its real size: one 640x480 image with 300 synthetic proposals drawn as
+    SURVEY.md §8(d) prescribes (cx,cy ~ U(image), w,h ~ LogU(8, min(W,H)), clipped, objectness sorted
+    descending) through the reference's own min_wh filter stand-in, _expand, _mask and _preprocess."""
+    ds = objects_mod.COCODataset.__new__(objects_mod.COCODataset)
+    ds._grid = 14
+    ds._expand_mode = objects_mod.ExpandMode.ADAPTIVE
+    ds.transforms = types.SimpleNamespace(transform=tv_transform)
+    w, h, n = 640, 480, 300
+    r = np.random.default_rng(21)
+    cx, cy = r.uniform(0, w, n), r.uniform(0, h, n)
+    bw = np.exp(r.uniform(np.log(8.0), np.log(float(min(w, h))), n))
+    bh = np.exp(r.uniform(np.log(8.0), np.log(float(min(w, h))), n))
+    x1, y1 = np.clip(cx - bw / 2, 0, w), np.clip(cy - bh / 2, 0, h)
+    x2, y2 = np.clip(cx + bw / 2, 0, w), np.clip(cy + bh / 2, 0, h)
+    score = np.sort(r.uniform(0, 1, n))[::-1]
+    prop = np.stack([x1, y1, x2, y2, score], 1).astype(np.float32)
+    ds._proposals = {0: torch.tensor(prop)}
+    batch = ds._preprocess(0, pathlib.Path('x.pth'), synth_image(w, h, 21))
+    p_ = BBoxesXYXY(torch.tensor(prop[:, :4]))
+    keep = p_.indices(min_wh=(4, 4))
+    exp = ds._expand(p_[keep], torch.tensor([w, h])).to_tensor()
+    np.savez_compressed(OUT / 'objects_300.npz', image_size=np.array([w, h]), proposals=prop,
+                        keep=keep.numpy(), expanded=exp.numpy(), bboxes=batch.bboxes.numpy(),
+                        objectness=batch.objectness.numpy(),
+                        masks=batch.masks.reshape(-1, 14, 14).to(torch.uint8).numpy(),
+                        n_objects=np.array(int(batch.objects.shape[0])))
+    print('objects_300:', int(batch.objects.shape[0]), 'objects of', n, 'proposals')
+
+
 def gen_hooks(objects_mod):
     import clip
     import clip.model
@@ -388,8 +418,12 @@ def main():
     load_ref('globals')
     blocks = load_ref('blocks')
     objects = load_ref('objects')
+    if '--only-objects-300' in sys.argv:  # add one fixture without re-minting the others
+        gen_objects_300(objects)
+        return
     gen_blocks(blocks)
     gen_objects(objects)
+    gen_objects_300(objects)
     gen_hooks(objects)
     import PIL
     (OUT / 'PROVENANCE.json').write_text(json.dumps(dict(
