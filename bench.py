@@ -150,8 +150,6 @@ class BlocksWork(_Work):
     name = 'blocks'
 
     def build(self, model):
-        import itertools
-
         import torch
         from oadp_amd.oake import blocks
         a = self.args
@@ -161,7 +159,6 @@ class BlocksWork(_Work):
         self.images = _synthetic_u8_images(a.batch, w, h, self.dev, seed=77 + self.rank)
         self.per_image = 1 + len(self.ds._level_tiles(w, h))
         self.units, self.crops = a.batch, a.batch * self.per_image
-        self._product = itertools.product
         self.buf = [torch.empty((self.crops, 3, 224, 224), dtype=torch.float16, device=self.dev)
                     for _ in range(a.lanes)]
         levels = len({t[2] for t in self.ds._level_tiles(w, h)})
@@ -170,33 +167,19 @@ class BlocksWork(_Work):
                          f'(block 0 = whole image) -> ViT-B/32 encode_image + L2-normalise + fp16 of all '
                          f'{self.crops} crops, encoder batches of {a.max_batch}; random-init weights')
 
-    def _device_blocks(self, v, image_u8, out):
-        # oadp_amd/oake/blocks.py::Validator._device_blocks on a bare dataset object
-        import torch
-        ds, level = self.ds, image_u8
-        h, w = level.shape[:2]
-        bboxes = [((w - h) / 2, 0, h, h) if w > h else (0, (h - w) / 2, w, w)]
-        v.crop_resize_normalize(level, [(0, 0, w, h)], out_dtype=torch.float16, out=out[0:1])
-        r, i, scale = ds._r, 1, 1.0
-        while True:
-            tiles = list(self._product(ds._partition(w), ds._partition(h)))
-            if not tiles:
-                break
-            bboxes.extend(ds._bbox(scale, x, y) for x, y in tiles)
-            v.crop_normalize(level, [(x, y, x + r, y + r) for x, y in tiles], out_dtype=torch.float16,
-                             out=out[i:i + len(tiles)])
-            i += len(tiles)
-            w, h = int(w / ds._rescale), int(h / ds._rescale)
-            scale *= ds._rescale
-            level = v.resize_u8(level, (w, h))
-        return bboxes
-
     def step(self, model):
         import torch
-        v, buf, k = model.visual, self.buf[model.visual.lane % len(self.buf)], self.per_image
-        for j, im in enumerate(self.images):
-            bboxes = self._device_blocks(v, im, buf[j * k:(j + 1) * k])
-        assert len(bboxes) == k
+        v, buf = model.visual, self.buf[model.visual.lane % len(self.buf)]
+        ds = self.ds
+        # host index math of the path (bboxes of every block, blocks.py:83-109) ...
+        for im in self.images:
+            h, w = im.shape[:2]
+            bboxes = [((w - h) / 2, 0, h, h) if w > h else (0, (h - w) / 2, w, w)]
+            bboxes.extend(ds._bbox(scale, x, y) for _, _, scale, x, y in ds._level_tiles(w, h))
+        assert len(bboxes) == self.per_image
+        # ... pyramids + crops of the whole batch on the device (one native call), then the encoder
+        v.blocks_batch(self.images, block_size=ds._r, max_stride=ds._s, rescale=ds._rescale,
+                       out_dtype=torch.float16, out=buf)
         return model.encode_image(buf, normalize=True, out_dtype=torch.float16)
 
     def cpu_baseline(self, seconds: float = 15.0) -> dict:

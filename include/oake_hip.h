@@ -22,6 +22,8 @@
  *                                                          -> oake_crop_normalize (exact-size crops),
  *                                                             oake_crop_resize_normalize (resampled)
  *   image.resize((w/1.5, h/1.5))      oadp/oake/blocks.py:72-76 -> oake_resize_u8
+ *   Dataset._preprocess (blocks)      oadp/oake/blocks.py:54-109 -> oake_blocks_batch (pyramid + every block
+ *                                                             crop of a whole flush of images)
  *
  * Conventions: plain C, int status (0 = OAKE_OK), no exception crosses the ABI.  All data
  * pointers named d_* are DEVICE pointers owned by the caller (e.g. a torch tensor's
@@ -180,6 +182,31 @@ OAKE_API int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, cons
                                      const int* heights, const int* widths, const float* h_boxes_xyxy,
                                      const int* counts, int out_size, int squash, const float* h_mean3,
                                      const float* h_std3, void* d_out, int out_dtype, void* stream);
+
+/* The same for the images of one flush: three launches in all (every box of every image is one job of
+ * the same coefficient / horizontal / vertical kernels). */
+
+/*
+ * Blocks mode in one call: for each of the n_images uint8 HWC RGB device images, what
+ * oadp/oake/blocks.py:89-109 (Dataset._preprocess) hands to the encoder —
+ *   row 0      preprocess(image)                      Resize(block_size, BICUBIC) + CenterCrop + Normalize
+ *   then       for every pyramid level (level 0 = the image, level k+1 = level k resized with Pillow's
+ *              bicubic filter to (int(w / rescale), int(h / rescale)), until a side is shorter than
+ *              block_size): the block_size x block_size crops at itertools.product(_partition(w),
+ *              _partition(h)) (x outer, y inner), each ToTensor + Normalize
+ * written image after image into d_out [sum of counts, 3, block_size, block_size] of out_dtype (F32|F16).
+ * counts_out[i] (optional) receives the number of rows of image i (= oake_blocks_count).  Pixels are
+ * bit-exact with the PIL / torchvision path; the index arithmetic is integer-exact with the reference's
+ * _partition / _partitions.  Work is batched by level across images: a flush costs about 4 launches per
+ * pyramid level, whatever the number of images.
+ */
+OAKE_API int oake_blocks_batch(oake_handle* h, int n_images, const uint8_t* const* d_images, const int* heights,
+                      const int* widths, int block_size, int max_stride, double rescale,
+                      const float* h_mean3, const float* h_std3, void* d_out, int out_dtype,
+                      int* counts_out, void* stream);
+/* Rows oake_blocks_batch produces for a width x height image (1 + tiles of every level); host only,
+ * -1 for invalid arguments. */
+OAKE_API int oake_blocks_count(int width, int height, int block_size, int max_stride, double rescale);
 
 /* PIL Image.resize((dw, dh)) (default BICUBIC) of a uint8 HWC RGB device image — the pyramid step of
  * oadp/oake/blocks.py:72-76 — bit-exact with Pillow. */

@@ -47,6 +47,9 @@ SIGNATURES = {
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), _VP, _I, _VP]),
     'oake_crop_resize_normalize_batch': (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, C.POINTER(C.c_float),
                                               C.POINTER(C.c_float), _VP, _I, _VP]),
+    'oake_blocks_batch': (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, C.c_double, C.POINTER(C.c_float),
+                               C.POINTER(C.c_float), _VP, _I, _VP, _VP]),
+    'oake_blocks_count': (_I, [_I, _I, _I, _I, C.c_double]),
     'oake_jpeg_info_batch': (_I, [_I, _VP, _VP, _VP, _VP, _VP]),
     'oake_resize_u8': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),
     'oake_text_default_config': (None, [_VP]),

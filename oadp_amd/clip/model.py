@@ -416,6 +416,47 @@ class VisionTransformer(_HookPoint):
             _lib.check(self._lib, h, rc, 'oake_crop_resize_normalize_batch')
         return out
 
+    def blocks_count(self, width: int, height: int, block_size: int = 224, max_stride: int = 112,
+                     rescale: float = 1.5) -> int:
+        n = self._lib.oake_blocks_count(int(width), int(height), int(block_size), int(max_stride), float(rescale))
+        if n < 0:
+            raise ValueError('bad block geometry')
+        return n
+
+    def blocks_batch(self, images_u8: list[torch.Tensor], *, block_size: int = 224, max_stride: int = 112,
+                     rescale: float = 1.5, out_dtype: torch.dtype = torch.float16,
+                     out: torch.Tensor | None = None) -> tuple[torch.Tensor, list[int]]:
+        """What the reference's blocks ``Dataset._preprocess`` (oadp/oake/blocks.py:89-109) produces for
+        every image of a flush — block 0 = preprocess(whole image), then the 224x224 blocks of every level
+        of the rescale pyramid — in ONE native call (``oake_blocks_batch``): bit-exact with the PIL path,
+        about four launches per pyramid level for the whole flush.  Returns ([sum k_i, 3, r, r], [k_i])."""
+        from .preprocess import CLIP_MEAN, CLIP_STD
+        if not images_u8:
+            return torch.empty((0, 3, block_size, block_size), dtype=out_dtype, device='cuda'), []
+        imgs, dev = [], None
+        for im in images_u8:
+            im, d = self._image_args(im)
+            if dev is not None and d != dev:
+                raise ValueError('all images must be on one device')
+            imgs.append(im)
+            dev = d
+        counts = [self.blocks_count(im.shape[1], im.shape[0], block_size, max_stride, rescale) for im in imgs]
+        out = self._crop_out(out, sum(counts), block_size, out_dtype, imgs[0].device)
+        m = len(imgs)
+        ptrs = (C.c_void_p * m)(*[im.data_ptr() for im in imgs])
+        hs = (C.c_int * m)(*[im.shape[0] for im in imgs])
+        ws = (C.c_int * m)(*[im.shape[1] for im in imgs])
+        got = (C.c_int * m)()
+        with torch.cuda.device(dev):
+            h = self._ensure_handle(dev)
+            mean, std = (C.c_float * 3)(*CLIP_MEAN), (C.c_float * 3)(*CLIP_STD)
+            rc = self._lib.oake_blocks_batch(h, m, ptrs, hs, ws, int(block_size), int(max_stride), float(rescale),
+                                             mean, std, out.data_ptr(), _TORCH2OAKE[out_dtype], got,
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            _lib.check(self._lib, h, rc, 'oake_blocks_batch')
+        assert list(got) == counts
+        return out, counts
+
     def resize_u8(self, image_u8: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
         """``PIL.Image.resize(size)`` (bicubic) of a uint8 HWC device image; ``size`` = (w, h)."""
         image_u8, dev = self._image_args(image_u8)

@@ -113,10 +113,14 @@ struct oake_handle {
   size_t rs_jobs_cap = 0, rs_coef_cap = 0, rs_bounds_cap = 0, rs_temp_cap = 0;
   // pinned staging ring for the job descriptors: the upload needs no host-side wait for the stream
   static constexpr int kJobRing = 8;
-  ResampleJob* rs_stage[kJobRing] = {};
+  void* rs_stage[kJobRing] = {};
   size_t rs_stage_cap[kJobRing] = {};
   hipEvent_t rs_stage_done[kJobRing] = {};
   int rs_stage_next = 0;
+  // oake_blocks_batch: crop descriptors and the pyramid levels >= 1 of a flush of images
+  CropJob* crop_jobs = nullptr;
+  uint8_t* pyr = nullptr;
+  size_t crop_jobs_cap = 0, pyr_cap = 0;
 
   // JPEG decode scratch (grown on demand): pinned host coefficients, device coefficients + planes
   int16_t* jp_host = nullptr;
@@ -306,7 +310,7 @@ void oake_destroy(oake_handle* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
-                  h->yn, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp,
+                  h->yn, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp, h->crop_jobs, h->pyr,
                   h->rowstat, h->rowpart, h->zero_mask, h->jp_coefs, h->jp_planes, h->tok_emb};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -824,13 +828,36 @@ int ksize_for(int in_size, int out_size) {
   return (int)std::ceil(2.0 * filterscale) * 2 + 1;  // Pillow: (int)ceil(support) * 2 + 1
 }
 
-// jobs -> device, scratch sizing, launch.  `jobs` offsets are filled here.
-int run_resample(oake_handle* h, hipStream_t s, const uint8_t* d_img, int height, int width,
-                 std::vector<ResampleJob>& jobs, int out_size, const float* mean3, const float* std3,
-                 void* d_out, int out_dtype) {
+// host descriptors -> a pinned ring slot -> device, asynchronously (a wait only if the slot's previous
+// upload, kJobRing calls ago, has not executed yet)
+int upload_async(oake_handle* h, hipStream_t s, const void* host, size_t bytes, void* d_dst) {
+  const int slot = h->rs_stage_next;
+  h->rs_stage_next = (slot + 1) % oake_handle::kJobRing;
+  if (!h->rs_stage_done[slot])
+    HIP_TRY(h, hipEventCreateWithFlags(&h->rs_stage_done[slot], hipEventDisableTiming));
+  else
+    HIP_TRY(h, hipEventSynchronize(h->rs_stage_done[slot]));
+  if (bytes > h->rs_stage_cap[slot]) {
+    if (h->rs_stage[slot]) HIP_TRY(h, hipHostFree(h->rs_stage[slot]));
+    h->rs_stage[slot] = nullptr;
+    h->rs_stage_cap[slot] = 0;
+    HIP_TRY(h, hipHostMalloc(&h->rs_stage[slot], bytes * 2, hipHostMallocDefault));
+    h->rs_stage_cap[slot] = bytes * 2;
+  }
+  std::memcpy(h->rs_stage[slot], host, bytes);
+  HIP_TRY(h, hipMemcpyAsync(d_dst, h->rs_stage[slot], bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipEventRecord(h->rs_stage_done[slot], s));
+  return OAKE_OK;
+}
+
+// jobs (each naming its source image) -> device, scratch sizing, three launches.  The offsets of `jobs`
+// are filled here.  out_dtype DT_U8: every job writes its own image to job.u8_out.
+int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, int out_size,
+                 const float* mean3, const float* std3, void* d_out, int out_dtype) {
+  if (jobs.empty()) return OAKE_OK;
   long coef = 0, bnd = 0, temp = 0;
   int max_out = 1;
-  long max_ch_rw = 1;
+  long max_ch_rw = 1, max_rh_rw = 1;
   for (auto& j : jobs) {
     j.kh = ksize_for(j.cw, j.rw);
     j.kv = ksize_for(j.ch, j.rh);
@@ -841,40 +868,66 @@ int run_resample(oake_handle* h, hipStream_t s, const uint8_t* d_img, int height
     j.temp_off = temp; temp += (long)j.ch * j.rw * 3;
     max_out = std::max(max_out, std::max(j.rw, j.rh));
     max_ch_rw = std::max(max_ch_rw, (long)j.ch * j.rw);
+    max_rh_rw = std::max(max_rh_rw, (long)j.rh * j.rw);
   }
-  if (max_ch_rw > 0x7fffffffL) return fail(h, OAKE_ERR_INVALID, "crop too large");
+  if (max_ch_rw > 0x7fffffffL || max_rh_rw > 0x7fffffffL) return fail(h, OAKE_ERR_INVALID, "crop too large");
   int rc;
   if ((rc = grow(h, s, &h->rs_jobs, &h->rs_jobs_cap, jobs.size() * sizeof(ResampleJob)))) return rc;
   if ((rc = grow(h, s, &h->rs_coef, &h->rs_coef_cap, (size_t)coef * 4))) return rc;
   if ((rc = grow(h, s, &h->rs_bounds, &h->rs_bounds_cap, (size_t)bnd * 4))) return rc;
   if ((rc = grow(h, s, &h->rs_temp, &h->rs_temp_cap, (size_t)temp))) return rc;
-  // descriptors -> a pinned ring slot -> device, asynchronously (a wait only if the slot's previous
-  // upload, 8 calls ago, has not executed yet)
-  {
-    const int slot = h->rs_stage_next;
-    h->rs_stage_next = (slot + 1) % oake_handle::kJobRing;
-    const size_t need = jobs.size() * sizeof(ResampleJob);
-    if (!h->rs_stage_done[slot])
-      HIP_TRY(h, hipEventCreateWithFlags(&h->rs_stage_done[slot], hipEventDisableTiming));
-    else
-      HIP_TRY(h, hipEventSynchronize(h->rs_stage_done[slot]));
-    if (need > h->rs_stage_cap[slot]) {
-      if (h->rs_stage[slot]) HIP_TRY(h, hipHostFree(h->rs_stage[slot]));
-      h->rs_stage[slot] = nullptr;
-      h->rs_stage_cap[slot] = 0;
-      HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->rs_stage[slot]), need * 2, hipHostMallocDefault));
-      h->rs_stage_cap[slot] = need * 2;
-    }
-    std::memcpy(h->rs_stage[slot], jobs.data(), need);
-    HIP_TRY(h, hipMemcpyAsync(h->rs_jobs, h->rs_stage[slot], need, hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipEventRecord(h->rs_stage_done[slot], s));
-  }
-  const double bytes = (double)temp * 2 + (double)jobs.size() * out_size * out_size * 3 * 4;
+  if ((rc = upload_async(h, s, jobs.data(), jobs.size() * sizeof(ResampleJob), h->rs_jobs))) return rc;
+  double bytes = (double)temp * 2;
+  if (out_dtype == DT_U8)
+    for (auto& j : jobs) bytes += (double)j.rh * j.rw * 3;
+  else
+    bytes += (double)jobs.size() * out_size * out_size * 3 * (out_dtype == DT_F32 ? 4 : 2);
   RUN(h, s, "resample", 0.0, bytes,
-      launch_resample(d_img, height, width, h->rs_jobs, (int)jobs.size(), max_out, (int)max_ch_rw,
-                      h->rs_coef, h->rs_bounds, h->rs_temp, out_size, mean3, std3, d_out, out_dtype,
-                      s));
+      launch_resample(h->rs_jobs, (int)jobs.size(), max_out, max_ch_rw, max_rh_rw, h->rs_coef, h->rs_bounds,
+                      h->rs_temp, out_size, mean3, std3, d_out, out_dtype, s));
   return OAKE_OK;
+}
+
+// `preprocess(image.crop(box))` geometry of one box: PIL Image.crop (every coordinate through Python
+// round(), ties to even; zero fill outside), then Resize(out_size, BICUBIC) + CenterCrop, or a squash.
+int fill_crop_job(oake_handle* h, ResampleJob& j, const uint8_t* img, int height, int width, const float* box,
+                  int out_size, int squash) {
+  j = ResampleJob{};
+  j.img = img; j.height = height; j.width = width;
+  const int x0 = (int)std::nearbyint((double)box[0]);
+  const int y0 = (int)std::nearbyint((double)box[1]);
+  const int x1 = (int)std::nearbyint((double)box[2]);
+  const int y1 = (int)std::nearbyint((double)box[3]);
+  j.sx0 = x0; j.sy0 = y0; j.cw = x1 - x0; j.ch = y1 - y0;
+  if (j.cw <= 0 || j.ch <= 0) return fail(h, OAKE_ERR_INVALID, "empty crop box");
+  if (squash) {
+    j.rw = j.rh = out_size;
+    j.cx = j.cy = 0;
+    return OAKE_OK;
+  }
+  // torchvision Resize(int) on a PIL image, then CenterCrop
+  if ((j.cw <= j.ch && j.cw == out_size) || (j.ch <= j.cw && j.ch == out_size)) {
+    j.rw = j.cw; j.rh = j.ch;
+  } else if (j.cw < j.ch) {
+    j.rw = out_size; j.rh = (int)((double)((long)out_size * j.ch) / (double)j.cw);
+  } else {
+    j.rh = out_size; j.rw = (int)((double)((long)out_size * j.cw) / (double)j.ch);
+  }
+  j.cy = (int)std::nearbyint((j.rh - out_size) / 2.0);
+  j.cx = (int)std::nearbyint((j.rw - out_size) / 2.0);
+  return OAKE_OK;
+}
+
+// Tile origins along one axis [REF oadp/oake/blocks.py:40-52]: nothing below r, [0] at r, else
+// n = ceil((length - r) / s) steps of near-equal integer size, the first `rem` steps one pixel longer.
+void partition_axis(int length, int r, int s, std::vector<int>& out) {
+  out.clear();
+  if (length < r) return;
+  out.push_back(0);
+  if (length == r) return;
+  const int n = (length - r - 1) / s + 1;
+  const int q = (length - r) / n, rem = (length - r) % n;
+  for (int i = 0; i < n; ++i) out.push_back(out.back() + q + (i < rem ? 1 : 0));
 }
 
 }  // namespace
@@ -1107,44 +1160,10 @@ int oake_crop_resize_normalize(oake_handle* h, const uint8_t* d_image_hwc, int h
                                const float* h_boxes_xyxy, int k, int out_size, int squash,
                                const float* h_mean3, const float* h_std3, void* d_out, int out_dtype,
                                void* stream) {
-  if (!h) return OAKE_ERR_INVALID;
-  if (k < 0 || height <= 0 || width <= 0 || out_size <= 0)
-    return fail(h, OAKE_ERR_INVALID, "bad crop geometry");
-  if (k == 0) return OAKE_OK;
-  if (!d_image_hwc || !h_boxes_xyxy || !d_out || !h_mean3 || !h_std3)
-    return fail(h, OAKE_ERR_INVALID, "null pointer");
-  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
-    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
-  HIP_TRY(h, hipSetDevice(h->device));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  std::vector<ResampleJob> jobs(k);
-  for (int i = 0; i < k; ++i) {
-    ResampleJob& j = jobs[i];
-    // PIL Image.crop: every coordinate through Python round() (ties to even), zero fill outside
-    const int x0 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 0]);
-    const int y0 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 1]);
-    const int x1 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 2]);
-    const int y1 = (int)std::nearbyint((double)h_boxes_xyxy[4 * i + 3]);
-    j.sx0 = x0; j.sy0 = y0; j.cw = x1 - x0; j.ch = y1 - y0;
-    if (j.cw <= 0 || j.ch <= 0) return fail(h, OAKE_ERR_INVALID, "empty crop box");
-    if (squash) {
-      j.rw = j.rh = out_size;
-      j.cx = j.cy = 0;
-    } else {
-      // torchvision Resize(int) on a PIL image, then CenterCrop
-      if ((j.cw <= j.ch && j.cw == out_size) || (j.ch <= j.cw && j.ch == out_size)) {
-        j.rw = j.cw; j.rh = j.ch;
-      } else if (j.cw < j.ch) {
-        j.rw = out_size; j.rh = (int)((double)((long)out_size * j.ch) / (double)j.cw);
-      } else {
-        j.rh = out_size; j.rw = (int)((double)((long)out_size * j.cw) / (double)j.ch);
-      }
-      j.cy = (int)std::nearbyint((j.rh - out_size) / 2.0);
-      j.cx = (int)std::nearbyint((j.rw - out_size) / 2.0);
-    }
-  }
-  return run_resample(h, s, d_image_hwc, height, width, jobs, out_size, h_mean3, h_std3, d_out,
-                      out_dtype);
+  const int counts[1] = {k};
+  const uint8_t* const imgs[1] = {d_image_hwc};
+  return oake_crop_resize_normalize_batch(h, 1, imgs, &height, &width, h_boxes_xyxy, counts, out_size, squash,
+                                          h_mean3, h_std3, d_out, out_dtype, stream);
 }
 
 int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, const uint8_t* const* d_images,
@@ -1152,23 +1171,34 @@ int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, const uint8_t
                                      const int* counts, int out_size, int squash, const float* h_mean3,
                                      const float* h_std3, void* d_out, int out_dtype, void* stream) {
   if (!h) return OAKE_ERR_INVALID;
-  if (n_images < 0) return fail(h, OAKE_ERR_INVALID, "negative image count");
+  if (n_images < 0 || out_size <= 0) return fail(h, OAKE_ERR_INVALID, "bad crop geometry");
   if (n_images == 0) return OAKE_OK;
-  if (!d_images || !heights || !widths || !h_boxes_xyxy || !counts || !d_out)
+  if (!d_images || !heights || !widths || !counts || !h_mean3 || !h_std3)
     return fail(h, OAKE_ERR_INVALID, "null pointer");
   if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
     return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
-  const size_t crop_bytes = (size_t)3 * out_size * out_size * (out_dtype == OAKE_F32 ? 4 : 2);
-  size_t done = 0;
+  size_t total = 0;
   for (int i = 0; i < n_images; ++i) {
     if (counts[i] < 0) return fail(h, OAKE_ERR_INVALID, "negative box count");
-    const int rc = oake_crop_resize_normalize(h, d_images[i], heights[i], widths[i], h_boxes_xyxy + 4 * done,
-                                              counts[i], out_size, squash, h_mean3, h_std3,
-                                              static_cast<char*>(d_out) + done * crop_bytes, out_dtype, stream);
-    if (rc != OAKE_OK) return rc;
-    done += (size_t)counts[i];
+    if (counts[i] > 0 && (!d_images[i] || heights[i] <= 0 || widths[i] <= 0))
+      return fail(h, OAKE_ERR_INVALID, "bad crop geometry");
+    total += (size_t)counts[i];
   }
-  return OAKE_OK;
+  if (total == 0) return OAKE_OK;
+  if (!h_boxes_xyxy || !d_out) return fail(h, OAKE_ERR_INVALID, "null pointer");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // the crops of ALL images as one job list: three launches per call, whatever the number of images
+  std::vector<ResampleJob> jobs(total);
+  size_t k = 0;
+  for (int i = 0; i < n_images; ++i)
+    for (int c = 0; c < counts[i]; ++c, ++k) {
+      const int rc = fill_crop_job(h, jobs[k], d_images[i], heights[i], widths[i], h_boxes_xyxy + 4 * k, out_size,
+                                   squash);
+      if (rc != OAKE_OK) return rc;
+      jobs[k].out_row = (long)k;
+    }
+  return run_resample(h, s, jobs, out_size, h_mean3, h_std3, d_out, out_dtype);
 }
 
 int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw, uint8_t* d_dst_hwc,
@@ -1180,9 +1210,125 @@ int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw, uin
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   std::vector<ResampleJob> jobs(1);
   ResampleJob& j = jobs[0];
+  j = ResampleJob{};
+  j.img = d_src_hwc; j.height = sh; j.width = sw;
   j.sx0 = j.sy0 = 0; j.cw = sw; j.ch = sh; j.rw = dw; j.rh = dh; j.cx = j.cy = 0;
+  j.u8_out = d_dst_hwc;
   const float z[3] = {0.f, 0.f, 0.f}, o[3] = {1.f, 1.f, 1.f};
-  return run_resample(h, s, d_src_hwc, sh, sw, jobs, 0, z, o, d_dst_hwc, OAKE_U8);
+  return run_resample(h, s, jobs, 0, z, o, nullptr, OAKE_U8);
+}
+
+int oake_blocks_count(int width, int height, int block_size, int max_stride, double rescale) {
+  if (width <= 0 || height <= 0 || block_size <= 0 || max_stride <= 0 || !(rescale > 1.0)) return -1;
+  std::vector<int> px, py;
+  long n = 1;  // block 0: the whole image
+  for (int w = width, hh = height;;) {
+    partition_axis(w, block_size, max_stride, px);
+    partition_axis(hh, block_size, max_stride, py);
+    if (px.empty() || py.empty()) break;
+    n += (long)px.size() * (long)py.size();
+    w = (int)((double)w / rescale);
+    hh = (int)((double)hh / rescale);
+  }
+  return n > 0x7fffffffL ? -1 : (int)n;
+}
+
+int oake_blocks_batch(oake_handle* h, int n_images, const uint8_t* const* d_images, const int* heights,
+                      const int* widths, int block_size, int max_stride, double rescale,
+                      const float* h_mean3, const float* h_std3, void* d_out, int out_dtype, int* counts_out,
+                      void* stream) {
+  if (!h) return OAKE_ERR_INVALID;
+  if (n_images < 0 || block_size <= 0 || block_size % 8 != 0 || max_stride <= 0 || !(rescale > 1.0))
+    return fail(h, OAKE_ERR_INVALID, "bad block geometry (block_size: positive multiple of 8; rescale > 1)");
+  if (n_images == 0) return OAKE_OK;
+  if (!d_images || !heights || !widths || !h_mean3 || !h_std3 || !d_out)
+    return fail(h, OAKE_ERR_INVALID, "null pointer");
+  if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
+    return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  for (int i = 0; i < n_images; ++i)
+    if (!d_images[i] || heights[i] <= 0 || widths[i] <= 0) return fail(h, OAKE_ERR_INVALID, "bad image");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int r = block_size;
+  const int odt = out_dtype == OAKE_F32 ? DT_F32 : DT_F16;
+
+  // ---- index math of the whole flush: the reference's _partitions walk (blocks.py:54-77) ----
+  struct Level {
+    int w, h;
+    std::vector<int> px, py;
+    size_t pyr_off;   // levels >= 1: byte offset of the level image in the pyramid arena
+    size_t first_row; // output row of the level's first crop
+  };
+  std::vector<std::vector<Level>> levels(n_images);
+  std::vector<size_t> block0_row(n_images);
+  size_t rows = 0, pyr_bytes = 0, max_levels = 0;
+  for (int i = 0; i < n_images; ++i) {
+    block0_row[i] = rows++;
+    int w = widths[i], hh = heights[i];
+    for (;;) {
+      Level lv;
+      lv.w = w; lv.h = hh; lv.pyr_off = 0; lv.first_row = rows;
+      partition_axis(w, r, max_stride, lv.px);
+      partition_axis(hh, r, max_stride, lv.py);
+      if (lv.px.empty() || lv.py.empty()) break;  // "halt when either side is below the block size"
+      rows += lv.px.size() * lv.py.size();
+      if (!levels[i].empty()) {
+        lv.pyr_off = pyr_bytes;
+        pyr_bytes += (((size_t)w * hh * 3) + 255) & ~(size_t)255;
+      }
+      levels[i].push_back(std::move(lv));
+      w = (int)((double)w / rescale);   // Python int(w / rescale): float division, truncation
+      hh = (int)((double)hh / rescale);
+    }
+    if (counts_out) counts_out[i] = (int)(rows - block0_row[i]);
+    max_levels = std::max(max_levels, levels[i].size());
+  }
+  int rc;
+  if ((rc = grow(h, s, &h->pyr, &h->pyr_cap, pyr_bytes))) return rc;
+
+  // ---- block 0 of every image = preprocess(whole image): Resize(r, BICUBIC) + CenterCrop(r) ----
+  std::vector<ResampleJob> jobs(n_images);
+  for (int i = 0; i < n_images; ++i) {
+    const float box[4] = {0.f, 0.f, (float)widths[i], (float)heights[i]};
+    if ((rc = fill_crop_job(h, jobs[i], d_images[i], heights[i], widths[i], box, r, 0))) return rc;
+    jobs[i].out_row = (long)block0_row[i];
+  }
+  if ((rc = run_resample(h, s, jobs, r, h_mean3, h_std3, d_out, odt))) return rc;
+
+  // ---- level by level: the exact-size crops of ALL images' level L in one launch, then the resizes
+  //      that make level L + 1 of all images (skipped where the next level has no tiles) ----
+  std::vector<CropJob> cjobs;
+  for (size_t L = 0; L < max_levels; ++L) {
+    cjobs.clear();
+    jobs.clear();
+    for (int i = 0; i < n_images; ++i) {
+      if (L >= levels[i].size()) continue;
+      const Level& lv = levels[i][L];
+      const uint8_t* src = L == 0 ? d_images[i] : h->pyr + lv.pyr_off;
+      long row = (long)lv.first_row;
+      for (int x : lv.px)  // itertools.product(partition(w), partition(h)): x outer, y inner
+        for (int y : lv.py) cjobs.push_back(CropJob{src, lv.h, lv.w, x, y, row++});
+      if (L + 1 < levels[i].size()) {
+        const Level& nx = levels[i][L + 1];
+        ResampleJob j{};
+        j.img = src; j.height = lv.h; j.width = lv.w;
+        j.cw = lv.w; j.ch = lv.h; j.rw = nx.w; j.rh = nx.h;
+        j.u8_out = h->pyr + nx.pyr_off;
+        jobs.push_back(j);
+      }
+    }
+    if (!cjobs.empty()) {
+      if ((rc = grow(h, s, &h->crop_jobs, &h->crop_jobs_cap, cjobs.size() * sizeof(CropJob)))) return rc;
+      if ((rc = upload_async(h, s, cjobs.data(), cjobs.size() * sizeof(CropJob), h->crop_jobs))) return rc;
+      RUN(h, s, "crop_normalize", 0.0, (double)cjobs.size() * r * r * 3 * (1 + (odt == DT_F32 ? 4 : 2)),
+          launch_crop_normalize_jobs(h->crop_jobs, (int)cjobs.size(), r, h_mean3, h_std3, d_out, odt, s));
+    }
+    if (!jobs.empty()) {
+      const float z[3] = {0.f, 0.f, 0.f}, o[3] = {1.f, 1.f, 1.f};
+      if ((rc = run_resample(h, s, jobs, 0, z, o, nullptr, DT_U8))) return rc;
+    }
+  }
+  return OAKE_OK;
 }
 
 int oake_jpeg_info(const uint8_t* h_data, size_t nbytes, int* height, int* width, int* components) {

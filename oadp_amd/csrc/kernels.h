@@ -136,7 +136,11 @@ hipError_t launch_crop_normalize(const uint8_t* img, int height, int width, cons
                                  void* out, int out_dtype, hipStream_t s);
 
 // ---- Pillow-exact crop + bicubic resize (resample.hip) --------------------------------------
+// One job = one crop of one uint8 HWC image; the jobs of a launch may come from different images
+// (a whole flush of a sweep is three launches, not three per image).
 struct ResampleJob {
+  const uint8_t* img;  // source image (device), uint8 HWC
+  int height, width;
   int sx0, sy0;        // crop origin in the source image (may be negative: PIL zero-fills)
   int cw, ch;          // crop size
   int rw, rh;          // size after Resize
@@ -145,12 +149,25 @@ struct ResampleJob {
   long coefh_off, coefv_off;    // offsets into the int32 coefficient table
   long boundh_off, boundv_off;  // offsets into the int32 bounds table
   long temp_off;       // byte offset of this job's horizontal-pass image
+  long out_row;        // DT_F32 / DT_F16 output: the job's row of `out` [rows,3,out,out]
+  uint8_t* u8_out;     // DT_U8 output: this job's rh x rw HWC destination (device)
 };
-// out_dtype DT_F32 / DT_F16: [njobs,3,out,out] normalised crops; DT_U8: one HWC uint8 image (rh x rw).
-hipError_t launch_resample(const uint8_t* img, int height, int width, const ResampleJob* d_jobs,
-                           int njobs, int max_out, int max_ch_rw, int32_t* d_coef, int32_t* d_bounds,
-                           uint8_t* d_temp, int out_size, const float* mean3, const float* std3,
-                           void* out, int out_dtype, hipStream_t s);
+// out_dtype DT_F32 / DT_F16: normalised crops, job j -> out[j.out_row];
+// DT_U8: every job writes its own uint8 HWC image (rh x rw) to job.u8_out (`out` unused).
+// max_ch_rw / max_rh_rw: the largest ch*rw / rh*rw over the jobs (grid sizing).
+hipError_t launch_resample(const ResampleJob* d_jobs, int njobs, int max_out, long max_ch_rw, long max_rh_rw,
+                           int32_t* d_coef, int32_t* d_bounds, uint8_t* d_temp, int out_size,
+                           const float* mean3, const float* std3, void* out, int out_dtype, hipStream_t s);
+
+// Exact-size crops (no resampling) of many images in one launch: job j -> out[j.out_row].
+struct CropJob {
+  const uint8_t* img;
+  int height, width;
+  int x1, y1;          // crop origin (PIL zero fill outside the image)
+  long out_row;
+};
+hipError_t launch_crop_normalize_jobs(const CropJob* d_jobs, int njobs, int out_size, const float* mean3,
+                                      const float* std3, void* out, int out_dtype, hipStream_t s);
 
 // ---- baseline JPEG decode (jpeg.hip) ---------------------------------------------------------
 enum { JPEG_OK = 0, JPEG_INVALID = 1, JPEG_UNSUPPORTED = 2 };

@@ -12,8 +12,10 @@
 //   * two passes, horizontal then vertical, with the intermediate image rounded and clipped to
 //     uint8 exactly like Pillow's temporary image;
 //   * the final uint8 pixel goes through ToTensor (/255) and Normalize ((x - mean) / std) in fp32.
-// One uint8 HWC source image is uploaded once; all crops of that image are produced by three kernel
-// launches (coefficients, horizontal, vertical+normalise).
+// A uint8 HWC source image is uploaded once; every job names its own source image, so all crops of a
+// whole flush of images are produced by three kernel launches (coefficients, horizontal,
+// vertical+normalise).  crop_normalize_jobs_kernel is the no-resampling special case (the 224x224 blocks
+// of a pyramid level): HBM-bound byte work, 8 pixels per thread, 16-byte stores per colour plane.
 #include "common.h"
 #include "kernels.h"
 
@@ -86,13 +88,13 @@ __device__ __forceinline__ uint8_t clip8(int v) {
 
 // Horizontal pass: temp[job][y][x][c] for y in [0,ch), x in [0,rw).  Source = crop window of the
 // HWC image with PIL's zero fill outside.  (Identity when cw == rw: Pillow skips the pass.)
-__global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ img, int height,
-                                                         int width,
-                                                         const ResampleJob* __restrict__ jobs,
+__global__ __launch_bounds__(256) void resample_h_kernel(const ResampleJob* __restrict__ jobs,
                                                          const int32_t* __restrict__ coef,
                                                          const int32_t* __restrict__ bounds,
                                                          uint8_t* __restrict__ temp) {
   const ResampleJob jb = jobs[blockIdx.y];
+  const uint8_t* __restrict__ img = jb.img;
+  const int height = jb.height, width = jb.width;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)jb.ch * jb.rw) return;
   const int y = idx / jb.rw, x = idx - (long)y * jb.rw;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ResampleJob* __re
     r = (float)v0; g = (float)v1; b = (float)v2;
   }
   const size_t plane = (size_t)out_size * out_size;
-  TOUT* o = out + (size_t)blockIdx.y * 3 * plane + p;
+  TOUT* o = out + (size_t)jb.out_row * 3 * plane + p;
   o[0] = (TOUT)((r / 255.0f - m0) / d0);
   o[plane] = (TOUT)((g / 255.0f - m1) / d1);
   o[2 * plane] = (TOUT)((b / 255.0f - m2) / d2);
@@ -175,14 +177,13 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ResampleJob* __re
 __global__ __launch_bounds__(256) void resample_v_u8_kernel(const ResampleJob* __restrict__ jobs,
                                                             const int32_t* __restrict__ coef,
                                                             const int32_t* __restrict__ bounds,
-                                                            const uint8_t* __restrict__ temp,
-                                                            uint8_t* __restrict__ out) {
-  const ResampleJob jb = jobs[0];
+                                                            const uint8_t* __restrict__ temp) {
+  const ResampleJob jb = jobs[blockIdx.y];
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (long)jb.rh * jb.rw) return;
   const int ry = p / jb.rw, rx = p - (long)ry * jb.rw;
   const uint8_t* tcol = temp + jb.temp_off + (long)rx * 3;
-  uint8_t* o = out + p * 3;
+  uint8_t* o = jb.u8_out + p * 3;
   if (jb.ch == jb.rh) {
     const uint8_t* q = tcol + (long)ry * jb.rw * 3;
     o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
@@ -203,21 +204,79 @@ __global__ __launch_bounds__(256) void resample_v_u8_kernel(const ResampleJob* _
   o[2] = clip8(s2);
 }
 
+// Exact-size crop + ToTensor + Normalize, many images per launch.  One thread = 8 consecutive pixels of
+// one output row, all three channels: 24 source bytes (contiguous in HWC) in, one 16-byte (f16) or two
+// 16-byte (f32) stores per colour plane out.  out_size must be a multiple of 8.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void crop_normalize_jobs_kernel(const CropJob* __restrict__ jobs,
+                                                                  int out_size, float m0, float m1, float m2,
+                                                                  float s0, float s1, float s2,
+                                                                  TOUT* __restrict__ out) {
+  const CropJob jb = jobs[blockIdx.y];
+  const int per_row = out_size >> 3;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= out_size * per_row) return;
+  const int oy = t / per_row, ox = (t - oy * per_row) << 3;
+  const int sy = jb.y1 + oy, sx = jb.x1 + ox;
+  float v[3][8];
+  const bool row_ok = sy >= 0 && sy < jb.height;
+  const uint8_t* rowp = jb.img + (size_t)(row_ok ? sy : 0) * jb.width * 3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int x = sx + i;
+    const bool ok = row_ok && x >= 0 && x < jb.width;  // PIL crop pads with zeros outside the image
+    const uint8_t* px = rowp + (size_t)(ok ? x : 0) * 3;
+    v[0][i] = ok ? (float)px[0] : 0.f;
+    v[1][i] = ok ? (float)px[1] : 0.f;
+    v[2][i] = ok ? (float)px[2] : 0.f;
+  }
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+  const size_t plane = (size_t)out_size * out_size;
+  TOUT* o = out + (size_t)jb.out_row * 3 * plane + (size_t)oy * out_size + ox;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    // ToTensor: /255 in fp32 ; Normalize: (x - mean) / std in fp32 — torchvision's operation order
+    alignas(16) TOUT r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (TOUT)((v[c][i] / 255.0f - mean[c]) / sd[c]);
+    if constexpr (sizeof(TOUT) == 2) {
+      *reinterpret_cast<uint4*>(o + c * plane) = *reinterpret_cast<const uint4*>(r);
+    } else {
+      *reinterpret_cast<uint4*>(o + c * plane) = *reinterpret_cast<const uint4*>(r);
+      *reinterpret_cast<uint4*>(o + c * plane + 4) = *reinterpret_cast<const uint4*>(r + 4);
+    }
+  }
+}
+
 }  // namespace
 
-hipError_t launch_resample(const uint8_t* img, int height, int width, const ResampleJob* d_jobs,
-                           int njobs, int max_out, int max_ch_rw, int32_t* d_coef, int32_t* d_bounds,
-                           uint8_t* d_temp, int out_size, const float* mean3, const float* std3,
-                           void* out, int out_dtype, hipStream_t s) {
+hipError_t launch_crop_normalize_jobs(const CropJob* d_jobs, int njobs, int out_size, const float* mean3,
+                                      const float* std3, void* out, int out_dtype, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  if (out_size <= 0 || out_size % 8 != 0) return hipErrorInvalidValue;
+  const dim3 g((out_size * (out_size / 8) + 255) / 256, njobs), b(256);
+  if (out_dtype == DT_F32)
+    hipLaunchKernelGGL(crop_normalize_jobs_kernel<float>, g, b, 0, s, d_jobs, out_size, mean3[0], mean3[1],
+                       mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<float*>(out));
+  else if (out_dtype == DT_F16)
+    hipLaunchKernelGGL(crop_normalize_jobs_kernel<f16_t>, g, b, 0, s, d_jobs, out_size, mean3[0], mean3[1],
+                       mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<f16_t*>(out));
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_resample(const ResampleJob* d_jobs, int njobs, int max_out, long max_ch_rw, long max_rh_rw,
+                           int32_t* d_coef, int32_t* d_bounds, uint8_t* d_temp, int out_size,
+                           const float* mean3, const float* std3, void* out, int out_dtype, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
   hipLaunchKernelGGL(resample_coeffs_kernel, dim3((max_out + 63) / 64, njobs, 2), dim3(64), 0, s,
                      d_jobs, njobs, d_coef, d_bounds);
-  hipLaunchKernelGGL(resample_h_kernel, dim3((max_ch_rw + 255) / 256, njobs), dim3(256), 0, s, img,
-                     height, width, d_jobs, d_coef, d_bounds, d_temp);
-  if (out_dtype == DT_U8) {
-    // whole-image resize (njobs == 1): max_out * max_out bounds rh * rw
-    hipLaunchKernelGGL(resample_v_u8_kernel, dim3(((long)max_out * max_out + 255) / 256), dim3(256), 0,
-                       s, d_jobs, d_coef, d_bounds, d_temp, reinterpret_cast<uint8_t*>(out));
+  hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((max_ch_rw + 255) / 256), njobs), dim3(256), 0, s,
+                     d_jobs, d_coef, d_bounds, d_temp);
+  if (out_dtype == DT_U8) {  // whole-image resizes: every job writes its own image
+    hipLaunchKernelGGL(resample_v_u8_kernel, dim3((unsigned)((max_rh_rw + 255) / 256), njobs), dim3(256), 0,
+                       s, d_jobs, d_coef, d_bounds, d_temp);
     return hipGetLastError();
   }
   const dim3 g((out_size * out_size + 255) / 256, njobs), b(256);

@@ -133,13 +133,15 @@ class Validator(BaseValidator[Batch]):
     def _encode(self, batches: list[Batch]):
         # reference _run_iter (blocks.py:125-135), crops of several images in one encoder pass
         if batches[0].blocks.dtype == torch.uint8:
+            # device preprocessing: pyramids + every block crop of the whole flush in one native call
+            # (oake_blocks_batch; `_device_blocks` is the same thing image by image, kept as its test twin)
+            ds = self._dataloader.dataset
             counts = [b.bboxes.shape[0] for b in batches]
-            r = self._dataloader.dataset._r
-            blocks = torch.empty((sum(counts), 3, r, r), dtype=torch.float16, device=self._device)
-            i = 0
-            for im, k in zip(self._images_u8([b.blocks for b in batches]), counts):
-                self._device_blocks(im, blocks[i:i + k])
-                i += k
+            blocks, got = self._model.visual.blocks_batch(
+                self._images_u8([b.blocks for b in batches]), block_size=ds._r, max_stride=ds._s,
+                rescale=ds._rescale, out_dtype=torch.float16)
+            if got != counts:
+                raise RuntimeError(f'{got} blocks cut, {counts} expected from the datasets\' bboxes')
         else:
             blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
             counts = [b.blocks.shape[0] for b in batches]

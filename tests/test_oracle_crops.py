@@ -166,3 +166,23 @@ def test_pil_crop_rounding():
     img = PIL.Image.new('RGB', (4, 4), (9, 9, 9))
     c = np.asarray(img.crop((-2, -2, 2, 2)))
     assert c[0, 0].tolist() == [0, 0, 0] and c[3, 3].tolist() == [9, 9, 9]
+
+
+def test_native_blocks_count_matches_reference_partitions(gb):
+    """oake_blocks_count / oake_blocks_batch restate _partition and the pyramid walk in C++ (host side of
+    the batched device path): integer-exact against the reference's own outputs and against the Python
+    twin on random sizes."""
+    import random
+    from oadp_amd import _lib
+    lib = _lib.load()
+    for im in gb['images']:
+        w, h = im['size']
+        assert lib.oake_blocks_count(w, h, 224, 112, 1.5) == im['n_blocks'], (w, h)
+    ds = pblocks.Dataset.__new__(pblocks.Dataset)
+    rnd = random.Random(5)
+    for r, s_, rescale in ((224, 112, 1.5), (224, 112, 1.25), (64, 48, 2.0)):
+        ds._r, ds._s, ds._rescale = r, s_, rescale
+        for _ in range(300):
+            w, h = rnd.randint(1, 2600), rnd.randint(1, 2600)
+            assert lib.oake_blocks_count(w, h, r, s_, rescale) == 1 + len(ds._level_tiles(w, h)), (w, h, r, s_, rescale)
+    assert lib.oake_blocks_count(0, 10, 224, 112, 1.5) == -1 and lib.oake_blocks_count(10, 10, 224, 112, 1.0) == -1

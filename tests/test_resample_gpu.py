@@ -72,3 +72,40 @@ def test_whole_image_preprocess_matches_pillow(visual, cuda, w, h):
     assert torch.equal(visual.crop_resize_normalize(d, box).cpu()[0], Preprocess(224, squash=False)(pil))
     assert torch.equal(visual.crop_resize_normalize(d, box, squash=True).cpu()[0],
                        Preprocess(224, squash=True)(pil))
+
+
+def test_blocks_batch_matches_per_image_path(cuda):
+    """oake_blocks_batch (pyramids + every block crop of a whole flush, batched by level across images) ==
+    the image-by-image composition of crop_resize_normalize / crop_normalize / resize_u8 that is itself
+    bit-identical to Pillow (tests above) — bit for bit, in both output types; 1700x1134 walks all five
+    levels, 100x90 has block 0 only, 224x224 exactly one tile."""
+    import itertools
+    from oadp_amd.oake import blocks
+    from oadp_amd import clip
+    from oadp_amd.weights import synthetic_state_dict
+    ds = blocks.Dataset.__new__(blocks.Dataset)
+    ds._r, ds._s, ds._rescale = 224, 112, 1.5
+    model, _ = clip.load(synthetic_state_dict(width=128, layers=1, heads=2, mlp_dim=256, embed_dim=64), max_batch=4)
+    v = model.visual
+    rng = np.random.default_rng(11)
+    sizes = [(640, 480), (1700, 1134), (100, 90), (224, 224), (500, 375), (337, 336), (480, 640)]
+    images = [torch.from_numpy(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).to(cuda) for w, h in sizes]
+    for dt in (torch.float16, torch.float32):
+        out, counts = v.blocks_batch(images, out_dtype=dt)
+        assert counts == [1 + len(ds._level_tiles(w, h)) for w, h in sizes]
+        i = 0
+        for im, (w, h), k in zip(images, sizes, counts):
+            ref = [v.crop_resize_normalize(im, [(0, 0, w, h)], out_dtype=dt)]
+            level, lw, lh = im, w, h
+            while True:
+                tiles = list(itertools.product(ds._partition(lw), ds._partition(lh)))
+                if not tiles:
+                    break
+                ref.append(v.crop_normalize(level, [(x, y, x + 224, y + 224) for x, y in tiles], out_dtype=dt))
+                lw, lh = int(lw / 1.5), int(lh / 1.5)
+                level = v.resize_u8(level, (lw, lh))
+            ref = torch.cat(ref)
+            assert ref.shape[0] == k
+            assert torch.equal(out[i:i + k], ref), (w, h, dt)
+            i += k
+        assert i == out.shape[0]
