@@ -251,15 +251,15 @@ class ObjectsWork(_Work):
     def step(self, model):
         import torch
         v, ds, mb = model.visual, self.ds, self.args.max_batch
-        objs, masks = [], []
-        for im, p in zip(self.images, self.props):
+        boxes_per_image, masks = [], []
+        for p in self.props:  # host index math of the path (objects.py:157-186): filter, expand, masks
             prop = p[:, :4]
             prop = prop[self._indices(prop, (4, 4))]
             boxes = ds._expand(prop, self.wh)
             fg = prop - torch.cat([boxes[:, :2], boxes[:, :2]], dim=1)
             masks.append(ds._masks(fg, boxes))
-            objs.append(v.crop_resize_normalize(im, boxes, out_dtype=torch.float16))
-        objs = torch.cat(objs)
+            boxes_per_image.append(boxes)
+        objs = v.crop_resize_normalize_batch(self.images, boxes_per_image, out_dtype=torch.float16)
         masks = torch.cat(masks).to(self.dev, non_blocking=True).half()
         embs = [v(objs[i:i + mb], masks[i:i + mb], normalize=True, out_dtype=torch.float16)
                 for i in range(0, objs.shape[0], mb)]

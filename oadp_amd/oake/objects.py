@@ -198,11 +198,11 @@ class Validator(BaseValidator[Batch]):
         # reference _run_iter (objects.py:316-338): mini-batches of `mini_batch_size` crops through
         # model.visual(objects, masks), normalise, cat, .half() x3
         if batches[0].crop_boxes is not None:
-            # device preprocessing: preprocess(image.crop(box)) for all proposals of an image in
-            # three kernel launches, bit-exact with the PIL path
-            objects = torch.cat([self._model.visual.crop_resize_normalize(
-                im, b.crop_boxes, out_dtype=torch.float16)
-                for im, b in zip(self._images_u8([b.objects for b in batches]), batches)])
+            # device preprocessing: preprocess(image.crop(box)) for all proposals of all images of the
+            # flush in three kernel launches, bit-exact with the PIL path
+            objects = self._model.visual.crop_resize_normalize_batch(
+                self._images_u8([b.objects for b in batches]), [b.crop_boxes for b in batches],
+                out_dtype=torch.float16)
         else:
             objects = torch.cat([b.objects for b in batches])
         masks = torch.cat([b.masks for b in batches])
