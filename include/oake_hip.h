@@ -343,12 +343,15 @@ OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
  *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default), 0..8 forced (csrc/gemm.hip)
  *   OAKE_OPT_GEMM_PANEL         GEMM tile order, as oake_debug_set_gemm_panel.  Default 0.
  *   OAKE_OPT_ATTENTION_VARIANT  bit set, as oake_debug_set_attention_variant.  Default 31.
+ *   OAKE_OPT_PATCH_DIRECT       conv1 gathers its patch rows straight from a 16-bit NCHW input batch (no
+ *                               im2col pass) where the geometry allows it.  0 = always im2col.  Default 1.
  */
 enum {
   OAKE_OPT_CLS_LAST = 1,
   OAKE_OPT_GEMM_VARIANT = 2,
   OAKE_OPT_GEMM_PANEL = 3,
-  OAKE_OPT_ATTENTION_VARIANT = 4
+  OAKE_OPT_ATTENTION_VARIANT = 4,
+  OAKE_OPT_PATCH_DIRECT = 5
 };
 OAKE_API int oake_set_option(oake_handle* h, int option, int value);
 OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);

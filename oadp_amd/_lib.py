@@ -10,6 +10,7 @@ OAKE_OK = 0
 OAKE_ERR_INVALID, OAKE_ERR_HIP, OAKE_ERR_STATE, OAKE_ERR_UNKNOWN_TENSOR, OAKE_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
 OAKE_OPT_CLS_LAST, OAKE_OPT_GEMM_VARIANT, OAKE_OPT_GEMM_PANEL, OAKE_OPT_ATTENTION_VARIANT = 1, 2, 3, 4
+OAKE_OPT_PATCH_DIRECT = 5
 ABI_VERSION = 2
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library

@@ -78,6 +78,7 @@ struct oake_handle {
   // oake_set_option: this handle's kernel-selection switches (nothing process-wide)
   LaunchOpts opts;
   int cls_last = 1;           // encode_image: last block for the CLS rows only (0 = all rows, as the reference)
+  int patch_direct = 1;       // conv1 reads 16-bit NCHW input directly (0 = always through im2col; A/B, tests)
 
   // weights
   void* conv_w = nullptr;     // [width, 3*P*P] 16-bit
@@ -680,14 +681,27 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   const oake_config& c = h->cfg;
   const int C = c.width, L = h->tokens;
   const size_t in_es = in_dtype == DT_F32 ? 4 : 2;
-  const double im_bytes = (double)nb * h->p2 * h->kpatch * 2 + (double)nb * 3 * c.image_size * c.image_size * in_es;
-  RUN(h, s, "im2col", 0.0, im_bytes,
-      launch_im2col(h->dt16, imgs, in_dtype, h->a_patch, nb, c.image_size, c.patch_size, c.stride,
-                    c.padding, h->grid, s));
   GemmArgs a{};
-  a.A = h->a_patch; a.W = h->conv_w; a.bias = nullptr; a.out = h->x;
+  a.W = h->conv_w; a.bias = nullptr; a.out = h->x;
   a.M = nb * h->p2; a.N = C; a.K = h->kpatch; a.ldo = C; a.pos = h->pos; a.P2 = h->p2; a.L = L;
   a.opts = &h->opts;
+  // Images already in the compute type (the reference casts to model.dtype before conv1; the device
+  // preprocessing writes fp16 crops): the conv1 GEMM's DMA waves gather the patch rows straight from the
+  // NCHW batch — no im2col pass, no a_patch round trip.  Other inputs (fp32, the other 16-bit type,
+  // strides that cut patches: objects mode) go through im2col, which also does the cast.
+  const bool direct = h->patch_direct && in_dtype == h->dt16 && h->xdt != DT_F32 &&
+                      gemm_patch_direct_ok(c.image_size, c.patch_size, c.stride, c.padding, a.M, a.N, a.K, &h->opts) &&
+                      reinterpret_cast<uintptr_t>(imgs) % 16 == 0;
+  if (direct) {
+    a.A = imgs;
+    a.patch_S = c.image_size; a.patch_P = c.patch_size; a.patch_G = h->grid;
+  } else {
+    const double im_bytes = (double)nb * h->p2 * h->kpatch * 2 + (double)nb * 3 * c.image_size * c.image_size * in_es;
+    RUN(h, s, "im2col", 0.0, im_bytes,
+        launch_im2col(h->dt16, imgs, in_dtype, h->a_patch, nb, c.image_size, c.patch_size, c.stride,
+                      c.padding, h->grid, s));
+    a.A = h->a_patch;
+  }
   RUNK(h, s, "gemm_conv1", 2.0 * a.M * a.N * a.K, 0.0,
       launch_gemm(h->dt16, h->xdt == DT_F32 ? EPI_PATCH : EPI_PATCH16, a, s));
   // 16-bit residual stream + every main-stream GEMM on the persistent kernel: LayerNorm statistics
@@ -1644,6 +1658,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
     case OAKE_OPT_GEMM_VARIANT: h->opts.gemm_variant = value < 0 ? -1 : value; return OAKE_OK;
     case OAKE_OPT_GEMM_PANEL: h->opts.gemm_panel = value; return OAKE_OK;
     case OAKE_OPT_ATTENTION_VARIANT: h->opts.attention_variant = value & 31; return OAKE_OK;
+    case OAKE_OPT_PATCH_DIRECT: h->patch_direct = value ? 1 : 0; return OAKE_OK;
     default: return fail(h, OAKE_ERR_INVALID, "unknown option " + std::to_string(option));
   }
 }
@@ -1655,6 +1670,7 @@ int oake_get_option(const oake_handle* h, int option, int* value) {
     case OAKE_OPT_GEMM_VARIANT: *value = h->opts.gemm_variant; return OAKE_OK;
     case OAKE_OPT_GEMM_PANEL: *value = h->opts.gemm_panel; return OAKE_OK;
     case OAKE_OPT_ATTENTION_VARIANT: *value = h->opts.attention_variant; return OAKE_OK;
+    case OAKE_OPT_PATCH_DIRECT: *value = h->patch_direct; return OAKE_OK;
     default: return OAKE_ERR_INVALID;
   }
 }

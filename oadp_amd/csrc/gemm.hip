@@ -58,6 +58,7 @@ struct EpiParams {
   const float2* rowpart_in;
   int nparts;
   float inv_k;            // 1 / K
+  int patch_S, patch_P, patch_G;  // A = NCHW image batch, gathered patch-wise (GemmArgs::patch_*); 0 = matrix
 };
 constexpr int kRowParts = 16;  // float2 slots per row (128 B): N <= 1024 residual width
 
@@ -125,20 +126,39 @@ __device__ __forceinline__ void tile_origin(const TileMap& tmap, int t, int BM, 
 // Per-lane source pointer of DMA piece `ii` (stage rows [8 ii, 8 ii + 8)): lane -> (row 8 ii +
 // lane/8, LDS chunk lane%8) fetching source chunk (lane%8) ^ ((row>>1)&7) of A row m0+row or of the
 // W row that sigma assigns to that LDS row.
+//
+// Patch-gather form (ep.patch_S != 0; conv1 without an im2col pass): A row m = (image, py, px) and a
+// K-tile is 64 / P rows of P pixels of one channel, so chunk c (8 pixels) of the K-tile starting at k0
+// lies at pixel row ky0 + (8 c) / P, column (8 c) % P of that patch — a per-lane part (here) plus a part
+// that depends only on the K-tile (patch_koff), exactly like the matrix form's kt * 128 bytes.
 template <typename T, int BM, int TN, bool PAIRED>
 __device__ __forceinline__ const char* piece_src(const T* A, const T* W, int M, int N, int K, int m0,
-                                                 int n0, int ii, int lane) {
+                                                 int n0, int ii, int lane, int pS = 0, int pP = 0,
+                                                 int pG = 0) {
   const int rr = 8 * ii + (lane >> 3);
   const int chunk = (lane & 7) ^ ((rr >> 1) & 7);
   if (rr < BM) {
     int gr = m0 + rr;
     gr = gr < M ? gr : M - 1;
+    if (pS != 0) {
+      const int img = gr / (pG * pG), p = gr - img * pG * pG;
+      const int py = p / pG, px = p - py * pG;
+      const int ky = (chunk * 8) / pP, kx = (chunk * 8) - ky * pP;
+      return reinterpret_cast<const char*>(A + (size_t)img * 3 * pS * pS + (size_t)(py * pP + ky) * pS + px * pP + kx);
+    }
     return reinterpret_cast<const char*>(A + (size_t)gr * K) + chunk * 16;
   }
   const int l = rr - BM;
   int gr = n0 + (l / TN) * TN + sigma_col<PAIRED>(l % TN);
   gr = gr < N ? gr : N - 1;
   return reinterpret_cast<const char*>(W + (size_t)gr * K) + chunk * 16;
+}
+
+// byte offset of K-tile kt in the patch-gather form: channel kt*64 / P^2, pixel row (kt*64 % P^2) / P
+__device__ __forceinline__ size_t patch_koff(int kt, int pS, int pP) {
+  const int k0 = kt * BK, pp = pP * pP;
+  const int ch = k0 / pp, ky0 = (k0 - ch * pp) / pP;
+  return ((size_t)ch * pS * pS + (size_t)ky0 * pS) * 2;
 }
 
 // Wave-level epilogue.  mbase = first row of the lane (m0 + wm*TM + lane&15), nwave = first column
@@ -880,8 +900,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       tile_origin(tmap, xb + xslot + tile_i * per_xcd, BM, BN, m0, n0);
 #pragma unroll
       for (int j = 0; j < NPL; ++j)
-        src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane);
+        src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane, ep.patch_S,
+                                              ep.patch_P, ep.patch_G);
     };
+    // pieces lw + NL j with j < kAPieces are A rows for every DMA wave (BM / 8 is a multiple of NL)
+    static_assert((BM / 8) % NL == 0, "A pieces split evenly over the DMA waves");
+    constexpr int kAPieces = BM / 8 / NL;
     // producer cursor: flat K-tile s_g (k position s_kt of tile s_tile) goes to ring slot s_buf
     int s_g = 0, s_kt = 0, s_tile = 0, s_buf = 0;
     // consumer position (compute group 0): K-tile d_kt of tile d_tile.  In the last phase of a tile's
@@ -914,8 +938,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     if (s_g < total) {                                                                       \
       char* _base = smem + s_buf * kStageBytes;                                              \
       const size_t _koff = (size_t)s_kt * (BK * 2);                                          \
+      const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P) : _koff; \
       _Pragma("unroll") for (int _j = (j0_); _j < (j1_); ++_j)                               \
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                     \
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
                                            (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0); \
     }                                                                                        \
   } while (0)
@@ -1210,7 +1235,7 @@ hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
                reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
-               a.nparts, 1.0f / (float)a.K};
+               a.nparts, 1.0f / (float)a.K, 0, 0, 0};
   OAKE_LAUNCH(kern, dim3(tmap.nwg), dim3(WM * WN * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
@@ -1232,7 +1257,7 @@ hipError_t launch_deep(const GemmArgs& a, hipStream_t s) {
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
                reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
-               a.nparts, 1.0f / (float)a.K};
+               a.nparts, 1.0f / (float)a.K, 0, 0, 0};
   OAKE_LAUNCH(kern, dim3(tmap.nwg), dim3(WM * WN * 64), lds, s, reinterpret_cast<const T*>(a.A),
               reinterpret_cast<const T*>(a.W), a.M, a.N, a.K, ep, tmap);
   return hipGetLastError();
@@ -1254,7 +1279,7 @@ hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
                reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
-               a.nparts, 1.0f / (float)a.K};
+               a.nparts, 1.0f / (float)a.K, 0, 0, 0};
   OAKE_LAUNCH(kern, dim3(tmap.nwg), dim3(512), lds, s, reinterpret_cast<const T*>(a.A),
               reinterpret_cast<const T*>(a.W), a.M, a.N, a.K, ep, tmap);
   return hipGetLastError();
@@ -1278,8 +1303,10 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
     num_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  if (a.K < 3 * BK)  // the EpiLds staging needs >= 3 K-tiles per tile
+  if (a.K < 3 * BK) {  // the EpiLds staging needs >= 3 K-tiles per tile
+    if (a.patch_S != 0) return hipErrorInvalidValue;
     return launch_simple<T, EPI, BM, BN, WM, WN>(a, s);
+  }
   const TileMap tmap = make_tilemap(a, BM, BN);
   int grid = (num_cu / 8) * 8;  // one persistent block per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
@@ -1288,7 +1315,11 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
                reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
-               a.nparts, 1.0f / (float)a.K};
+               a.nparts, 1.0f / (float)a.K, 0, 0, 0};
+  if (a.patch_S != 0) {
+    if (EPI != EPI_PATCH16 && EPI != EPI_PATCH) return hipErrorInvalidValue;
+    ep.patch_S = a.patch_S; ep.patch_P = a.patch_P; ep.patch_G = a.patch_G;
+  }
   OAKE_LAUNCH(kern, dim3(grid), dim3((WM * WN + 4) * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
                      a.K, ep, tmap);
@@ -1362,8 +1393,18 @@ bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts) {
   return (v == 4 || v == 8) && K >= 3 * BK;
 }
 
+bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,
+                          const LaunchOpts* opts) {
+  // 8-pixel chunks stay inside a patch row, a K-tile is whole patch rows of one channel, every chunk is
+  // 16-byte aligned, and the shape runs the persistent kernel (the only one with the gather)
+  return stride == patch && padding == 0 && image % patch == 0 && patch % 8 == 0 && BK % patch == 0 &&
+         (patch * patch) % BK == 0 && image % 8 == 0 && K == 3 * patch * patch &&
+         gemm_uses_persistent(M, N, K, opts);
+}
+
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+  if (a.patch_S != 0 && !gemm_uses_persistent(a.M, a.N, a.K, a.opts)) return hipErrorInvalidValue;
   if (a.K % BK != 0 || a.N % 4 != 0 || a.ldo % 4 != 0) return hipErrorInvalidValue;
   if ((epi == EPI_T16_BIAS || epi == EPI_T16_GELU || epi == EPI_RESID16 || epi == EPI_PATCH16 ||
        epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN || epi == EPI_T16_NONE || epi == EPI_T16_RAW) &&

@@ -59,7 +59,15 @@ struct GemmArgs {
   const float* rowpart_in;
   int nparts;
   const LaunchOpts* opts;  // nullptr = defaults
+  // EPI_PATCH16 on the persistent kernel only: A is not a matrix but the 16-bit NCHW image batch itself
+  // ([n,3,S,S], conv stride == patch P, no padding, grid G = S / P): row m = (image, py, px) of the implicit
+  // im2col matrix, column k = (channel, ky, kx); the DMA waves gather the patch rows straight from the
+  // images (8 pixels = 16 B per lane, source-side swizzle as for a matrix).  patch_S == 0: plain matrix A.
+  int patch_S, patch_P, patch_G;
 };
+// true when the conv1 GEMM can read its A operand straight from the NCHW batch (no im2col pass)
+bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,
+                          const LaunchOpts* opts = nullptr);
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
 // true when launch_gemm runs this shape on the persistent kernel (row statistics via rowpart_*)

@@ -217,6 +217,36 @@ def test_last_block_for_cls_rows_only_is_exact_elimination(cuda, cfg, n, resid32
     _check(full, ref, 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_conv1_patch_gather_equals_im2col(cuda, dtype):
+    """Input already in the compute type (what the reference hands to conv1 after `.type(model.dtype)`, and what
+    the device preprocessing writes): the conv1 GEMM gathers its patch rows straight from the NCHW batch.
+    Same operand bits, same kernel, same tile order as the im2col route => bit-identical features; and
+    within tolerance of the oracle.  45 crops leave a ragged last tile, 300 crops run three passes."""
+    sd = synthetic_state_dict()
+    direct, _ = clip.load(sd, compute_dtype=dtype, max_batch=128)
+    via_im2col, _ = clip.load(sd, compute_dtype=dtype, max_batch=128)
+    via_im2col.visual.set_option('patch_direct', 0)
+    for n in (128, 45, 300):
+        x = synthetic_images(n if n <= 128 else 100, seed=7 + n).to(dtype)
+        if n > 128:
+            x = x.repeat(3, 1, 1, 1)
+        xd = x.to(cuda)
+        a = direct.encode_image(xd, normalize=True, out_dtype=torch.float32)
+        b = via_im2col.encode_image(xd, normalize=True, out_dtype=torch.float32)
+        assert torch.equal(a, b), n
+        # a view with a 16-byte-misaligned base falls back to im2col and still agrees
+        if n == 45:
+            ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x[:6].float()))
+            _check(a[:6], ref, *((1e-3, 1e-3) if dtype == torch.float16 else (2e-2, 8e-3)))
+    prof = direct.visual
+    prof.profile(True)
+    direct.encode_image(synthetic_images(64, seed=1).to(dtype).to(cuda))
+    names = {p_['name'] for p_ in prof.profile_read()}
+    prof.profile(False)
+    assert 'im2col' not in names and 'gemm_conv1' in names
+
+
 def test_batches_beyond_1024_crops_per_pass(cuda):
     """max_batch > 1024: the CLS rows of the last block (M = crops per pass) are then large enough for the
     persistent GEMM, which takes its LayerNorm statistics as per-row sums — decided per GEMM from the shape
