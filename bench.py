@@ -351,7 +351,7 @@ def main() -> int:
         dev = torch.device('cuda', local % ngpu)
     if dist:
         import torch.distributed as td
-        td.init_process_group(backend=backend)
+        td.init_process_group(backend=backend)  # (torch.cuda.set_device above: RCCL uses this rank's GPU)
         assert td.get_world_size() == args.gpus, (td.get_world_size(), args.gpus)
         ones = torch.ones(1, dtype=torch.float64, device=dev)
         td.all_reduce(ones)  # the collective library itself sees N ranks
