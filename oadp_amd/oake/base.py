@@ -173,16 +173,49 @@ def atomic_save(obj: Any, path: pathlib.Path) -> None:
 
 
 class _HostCopy:
-    """A device -> host copy in flight: ``get()`` waits for it and returns the host tensor."""
+    """A device -> host copy in flight: ``get()`` waits for it and returns the host tensor.  The pinned
+    staging buffer belongs to THIS copy until then (``_PinnedPool``): however many copies a subclass starts
+    per flush, and however deep the look-ahead, none can overwrite a result that has not been taken yet."""
 
-    def __init__(self, tensor: torch.Tensor, event: 'torch.cuda.Event | None') -> None:
-        self._tensor, self._event = tensor, event
+    def __init__(self, tensor: torch.Tensor, event: 'torch.cuda.Event | None' = None,
+                 pool: '_PinnedPool | None' = None, slot: int = -1) -> None:
+        self._tensor, self._event, self._pool, self._slot = tensor, event, pool, slot
 
     def get(self) -> torch.Tensor:
         if self._event is not None:
             self._event.synchronize()
             self._event = None
+        if self._pool is not None:  # private copy out of the pinned slot, which goes back to the pool
+            self._tensor = self._tensor.clone()
+            self._pool.release(self._slot)
+            self._pool = None
         return self._tensor
+
+
+class _PinnedPool:
+    """Pinned host buffers for asynchronous device -> host copies; a buffer is handed out to one copy at a
+    time and returns when that copy's result has been taken (a new one is allocated if all are in flight)."""
+
+    def __init__(self) -> None:
+        self._bufs: list[torch.Tensor] = []
+        self._busy: list[bool] = []
+
+    def acquire(self, numel: int, dtype: torch.dtype) -> tuple[int, torch.Tensor]:
+        for i, (buf, busy) in enumerate(zip(self._bufs, self._busy)):
+            if not busy and buf.dtype == dtype and buf.numel() >= numel:
+                self._busy[i] = True
+                return i, buf
+        for i, busy in enumerate(self._busy):  # a free buffer of the wrong size / type: replace it
+            if not busy:
+                self._bufs[i] = torch.empty(max(numel, 1), dtype=dtype, pin_memory=True)
+                self._busy[i] = True
+                return i, self._bufs[i]
+        self._bufs.append(torch.empty(max(numel, 1), dtype=dtype, pin_memory=True))
+        self._busy.append(True)
+        return len(self._bufs) - 1, self._bufs[-1]
+
+    def release(self, slot: int) -> None:
+        self._busy[slot] = False
 
 
 class AsyncWriter:
@@ -296,8 +329,7 @@ class BaseValidator(ABC, Generic[T]):
         self._prefetch = prefetch
         self._writer: AsyncWriter | None = None
         self._inflight: tuple[list, Any] | None = None   # the flush whose results are still on the GPU
-        self._host_bufs: list[torch.Tensor | None] = [None, None]
-        self._host_slot = 0
+        self._host_pool = _PinnedPool()
         # consecutive flushes alternate over `streams` lanes = (native handle, HIP stream) pairs: the
         # kernels of two independent batches fill each other's start-up and tail (GPU only)
         self._n_lanes = max(1, int(streams)) if self._device.type == 'cuda' and hasattr(
@@ -350,20 +382,17 @@ class BaseValidator(ABC, Generic[T]):
 
     def _to_host(self, t: torch.Tensor) -> '_HostCopy':
         """Start the device -> host copy of an encoder output without waiting for it (``_encode`` may
-        return a closure that calls ``.get()``: see ``_flush``).  Two pinned buffers alternate, so a
-        result must be cloned out of the returned tensor before the flush after next starts its copy."""
+        return a closure that calls ``.get()``: see ``_flush``).  The pinned staging buffer is owned by the
+        returned copy until ``.get()`` (``_PinnedPool``)."""
         if not t.is_cuda:
-            return _HostCopy(t, None)
-        n, slot = t.numel(), self._host_slot
-        self._host_slot ^= 1
-        buf = self._host_bufs[slot]
-        if buf is None or buf.numel() < n or buf.dtype != t.dtype:
-            buf = self._host_bufs[slot] = torch.empty(max(n, 1), dtype=t.dtype, pin_memory=True)
+            return _HostCopy(t)
+        n = t.numel()
+        slot, buf = self._host_pool.acquire(n, t.dtype)
         dst = buf[:n].view(t.shape)
         dst.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return _HostCopy(dst, ev)
+        return _HostCopy(dst, ev, self._host_pool, slot)
 
     def _submit(self, batches: list[T], results: list) -> None:
         assert self._writer is not None

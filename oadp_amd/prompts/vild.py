@@ -53,14 +53,19 @@ def adaptively_tokenize(texts: Iterable[str], encode: Callable[[str], Sequence[i
 
 
 def embed(model, categories: Sequence[str], encode: Callable[[str], Sequence[int]], *,
-          device: torch.device | str = 'cuda', prompts: Sequence[str] | None = None, **tok) -> dict:
+          device: torch.device | str = 'cuda', prompts: Sequence[str] | None = None,
+          dtype: torch.dtype = torch.float32, **tok) -> dict:
+    """The reference's loop (oadp/prompts/vild.py:60-71): per template, encode_text -> F.normalize; mean over
+    the templates.  ``dtype``: element type of the saved ``embeddings``.  The reference saves whatever
+    ``model.encode_text`` returns — fp16 when its CLIP runs on a GPU, fp32 on the CPU; the template mean is
+    accumulated in fp32 here either way (default fp32 out; pass ``torch.float16`` for the GPU reference's file)."""
     total = None
     prompts = list(prompts) if prompts is not None else templates()
     for prompt in prompts:
         tokens = adaptively_tokenize(map(prompt.format, categories), encode, **tok)
         e = model.encode_text(tokens.to(device), normalize=True, out_dtype=torch.float32)  # F.normalize fused
         total = e if total is None else total + e
-    return dict(embeddings=(total / len(prompts)).cpu(), names=list(categories))
+    return dict(embeddings=(total / len(prompts)).to(dtype).cpu(), names=list(categories))
 
 
 def main(categories: Sequence[str], encode: Callable[[str], Sequence[int]], *, model=None,
