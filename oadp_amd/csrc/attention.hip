@@ -600,6 +600,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     *reinterpret_cast<uint4*>(vs + (lr + 32) * kVStride + lc * 8) = vreg1;                   \
   } while (0)
 
+  // Work that only pads is skipped in whole 16-row tiles (wave-uniform branches): a wave with n valid
+  // queries runs ceil(n / 16) of its two query tiles (L = 197: the last block's third wave has 5 queries,
+  // the object token's wave needs one tile), and a chunk with n valid keys ceil(n / 16) of its four key
+  // tiles and ceil(n / 32) of its two PV halves (L = 197: the fourth chunk holds 5 keys; L = 77: 13).
+  const int nmt = is_obj ? 1 : (q0 >= L ? 0 : (L - q0 > 16 ? 2 : 1));
   const int nchunks = (L + 63) >> 6;
   OAKE_FETCH(0);
   for (int kc = 0; kc < nchunks; ++kc) {
@@ -609,6 +614,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (kc + 1 < nchunks) OAKE_FETCH(k0 + 64);  // in flight under this chunk's arithmetic
     // a chunk entirely after this wave's last query is masked out completely under the causal mask
     const bool skip = !active || (causal && !is_obj && k0 > q0 + 31);
+    const int nkt = L - k0 >= 64 ? 4 : (L - k0 + 15) >> 4;  // key tiles of this chunk with a valid key
+    const int nks = (nkt + 1) >> 1;
     if (!skip) {
       f32x4 sacc[4][MT];
 #pragma unroll
@@ -616,20 +623,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) {
+        if (kt < nkt) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const vec8 kf = *reinterpret_cast<const vec8*>(ks + (kt * 16 + fr) * kVStride + kk * 32 + g * 8);
+          for (int kk = 0; kk < 2; ++kk) {
+            const vec8 kf = *reinterpret_cast<const vec8*>(ks + (kt * 16 + fr) * kVStride + kk * 32 + g * 8);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
+            for (int mt = 0; mt < MT; ++mt)
+              if (mt < nmt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
+          }
         }
+      }
       vec8 pf[MT][2];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        if (mt >= nmt) continue;
         float mx = -1e30f;
         if (is_obj) {  // (one scalar branch around the whole tile, not one per score)
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
+          for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nkt) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int key = k0 + kt * 16 + 4 * g + r;
@@ -639,9 +652,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
               sacc[kt][mt][r] = sv;
               mx = fmaxf(mx, sv);
             }
+          }
         } else {
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
+          for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nkt) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int key = k0 + kt * 16 + 4 * g + r;
@@ -651,6 +666,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
               sacc[kt][mt][r] = sv;
               mx = fmaxf(mx, sv);
             }
+          }
         }
         mx = rows16_max(mx);
         const float m_new = fmaxf(m_run[mt], mx);
@@ -658,13 +674,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float nb = -m_new * kLog2e;  // exp(s - m) = 2^(s log2(e) - m log2(e)): one FMA + v_exp_f32
         float sum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) {
+          if (kt < nkt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][mt][r], kLog2e, nb));
-            sacc[kt][mt][r] = p;
-            sum += p;
+            for (int r = 0; r < 4; ++r) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][mt][r], kLog2e, nb));
+              sacc[kt][mt][r] = p;
+              sum += p;
+            }
+          } else {
+            sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};  // P of a key tile without valid keys is exactly 0
           }
+        }
         sum = rows16_sum(sum);
         l_run[mt] = l_run[mt] * alpha + sum;
         m_run[mt] = m_new;
@@ -684,7 +705,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
       }
 #pragma unroll
-      for (int ksx = 0; ksx < 2; ++ksx)
+      for (int ksx = 0; ksx < 2; ++ksx) {
+        if (ksx >= nks) continue;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const int sub = fr >> 2, c4 = (fr & 3) * 4;
@@ -698,8 +720,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
           const vec8 vf = __builtin_bit_cast(vec8, both);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ksx], oacc[dt][mt]);
+          for (int mt = 0; mt < MT; ++mt)
+            if (mt < nmt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ksx], oacc[dt][mt]);
         }
+      }
     }
     __syncthreads();  // every wave is done with this chunk's K / V before the next publish
   }
@@ -736,6 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   T* stage = ((wid & 2) ? vs : ks) + (wid & 1) * 32 * kVStride;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    if (mt >= nmt) continue;
     const float inv = 1.0f / l_run[mt];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {

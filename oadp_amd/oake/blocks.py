@@ -3,6 +3,7 @@ dict(embeddings [K,512] f16, bboxes [K,4] f16).  Reference: oadp/oake/blocks.py.
 from __future__ import annotations
 
 import itertools
+import os
 import pathlib
 from typing import Generator, NamedTuple
 
@@ -137,11 +138,18 @@ class Validator(BaseValidator[Batch]):
             # (oake_blocks_batch; `_device_blocks` is the same thing image by image, kept as its test twin)
             ds = self._dataloader.dataset
             counts = [b.bboxes.shape[0] for b in batches]
-            blocks, got = self._model.visual.blocks_batch(
-                self._images_u8([b.blocks for b in batches]), block_size=ds._r, max_stride=ds._s,
-                rescale=ds._rescale, out_dtype=torch.float16)
-            if got != counts:
-                raise RuntimeError(f'{got} blocks cut, {counts} expected from the datasets\' bboxes')
+            images = self._images_u8([b.blocks for b in batches])
+            if os.environ.get('OAKE_BLOCKS_PER_IMAGE'):  # A/B switch: the image-by-image composition
+                blocks = torch.empty((sum(counts), 3, ds._r, ds._r), dtype=torch.float16, device=self._device)
+                i = 0
+                for im, k in zip(images, counts):
+                    self._device_blocks(im, blocks[i:i + k])
+                    i += k
+            else:
+                blocks, got = self._model.visual.blocks_batch(images, block_size=ds._r, max_stride=ds._s,
+                                                              rescale=ds._rescale, out_dtype=torch.float16)
+                if got != counts:
+                    raise RuntimeError(f'{got} blocks cut, {counts} expected from the datasets\' bboxes')
         else:
             blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
             counts = [b.blocks.shape[0] for b in batches]
