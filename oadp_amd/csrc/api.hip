@@ -113,7 +113,7 @@ struct oake_handle {
   uint8_t* rs_temp = nullptr;
   size_t rs_jobs_cap = 0, rs_coef_cap = 0, rs_bounds_cap = 0, rs_temp_cap = 0;
   // pinned staging ring for the job descriptors: the upload needs no host-side wait for the stream
-  static constexpr int kJobRing = 8;
+  static constexpr int kJobRing = 32;  // (a 6-level blocks flush makes 13 uploads: no slot is reused within a call)
   void* rs_stage[kJobRing] = {};
   size_t rs_stage_cap[kJobRing] = {};
   hipEvent_t rs_stage_done[kJobRing] = {};
