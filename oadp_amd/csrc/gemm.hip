@@ -844,7 +844,7 @@ __global__ __launch_bounds__(512) void gemm_q4_kernel(const T* __restrict__ A, c
 //     straight across tile boundaries, so there is no per-tile prologue and the epilogue's stores
 //     drain under the next tile's MFMAs.
 // Measured: 1520 cycles per K-tile in the loop = 84 % MFMA utilisation.
-template <typename T, int EPI, int BM, int BN, int WM, int WN>
+template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false>
 __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __restrict__ A,
                                                                      const T* __restrict__ W, int M,
                                                                      int N, int K, EpiParams ep,
@@ -912,10 +912,13 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     // FIRST K-tile (group 1 finished the previous tile's epilogue two phases earlier) one DMA wave
     // each stages the tile's bias / colsum block into the EpiLds area; it is covered by
     // the next iteration's vmcnt wait + barrier, long before the tile's epilogue (nk >= 3).
+    // (Two long phases per K-tile: group 1's epilogue of the previous tile runs IN the last phase of the
+    // first K-tile, so the block is staged one K-tile later.)
+    constexpr int kEpiStageKt = PH2 ? 1 : 0;
     int d_kt = 0, d_tile = 0;
 #define OAKE_STAGE_EPI()                                                                        \
   do {                                                                                          \
-    if (d_kt == 0) {                                                                            \
+    if (d_kt == kEpiStageKt) {                                                                  \
       int _m0, _n0;                                                                             \
       tile_origin(tmap, xb + xslot + d_tile * per_xcd, BM, BN, _m0, _n0);                       \
       char* _e = smem + NSTAGE * kStageBytes;                                                   \
@@ -1006,6 +1009,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
           st_shift = -_mean * st_rstd;
         }
       }
+      if constexpr (PH2) {  // two long phases per K-tile: half of the pieces in each
+        static_assert(!PH2 || !LN, "the long-phase schedule serves the epilogues without LayerNorm statistics");
+        OAKE_STAGE(0, Q2);
+        OAKE_BAR();
+        OAKE_STAGE(Q2, NPL);
+      } else {
       OAKE_STAGE(0, Q1);  // flat K-tile g+2, a quarter of the pieces per phase
       OAKE_BAR();
       OAKE_STAGE(Q1, Q2);
@@ -1021,6 +1030,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       OAKE_STAGE(Q2, Q3);
       OAKE_BAR();
       OAKE_STAGE(Q3, NPL);
+      }
       OAKE_STAGE_EPI();
       const bool newer = g + 2 < total;
       OAKE_ADVANCE();
@@ -1047,7 +1057,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   const int koff1 = ((1 * 4 + fg) ^ fsw) << 4;
   const char* elds = smem + NSTAGE * kStageBytes;
   // (cycle stamps are compiled out of the LN-folded variants: they sit exactly at the VGPR limit)
-  unsigned long long* const trace = EpiTraits<EPI>::kLn ? nullptr : tmap.trace;
+  unsigned long long* const trace = (EpiTraits<EPI>::kLn || PH2) ? nullptr : tmap.trace;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -1082,7 +1092,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   // pending (packed, not yet stored) 16-bit tile: see tile_pack_paired
   constexpr int MI0 = 1;  // rows stored immediately at tile end: the K-loop holds acc + fragments +
                           // (MI - MI0) * NI/2 * 4 pending registers inside 168 VGPRs (3 waves per SIMD)
-  constexpr bool TRICKLE = EpiTraits<EPI>::kTrickle;
+  constexpr bool TRICKLE = EpiTraits<EPI>::kTrickle && !PH2;  // (long phases: the second fragment set takes the pending tile's registers)
   constexpr int NPEND = TRICKLE ? (MI - MI0) * (NI / 2) : 1;
   uint4 pend[TRICKLE ? MI - MI0 : 1][TRICKLE ? NI / 2 : 1];
   T* pend_ptr = nullptr;  // lane's address of the tile's first row-block (mi = 0, t = 0)
@@ -1098,6 +1108,29 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   int c_buf = 0, c_kt = 0, c_tile = 0;
   unsigned long long t_tile = trace ? __builtin_readcyclecounter() : 0;
   for (int g = 0; g < total; ++g) {
+    if constexpr (PH2) {
+      // two long phases per K-tile (18 fragment reads | 40 MFMAs): half the barrier hand-overs, for the
+      // epilogues that keep nothing pending across the K loop and can spare the second fragment set
+      vec8 af1[MI], bf1[NI];
+      {
+        const char* _st = smem + c_buf * kStageBytes;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bf[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af1[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bf1[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff1);
+      }
+      OAKE_LGKM0();
+      OAKE_BAR();
+      OAKE_MFMA_BLOCK();
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf1[ni], af1[mi], acc[mi][ni]);
+    } else {
     OAKE_LOAD_FRAGS(c_buf, koff0);
     OAKE_LGKM0();
     OAKE_BAR();
@@ -1116,6 +1149,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     }
     OAKE_BAR();
     OAKE_MFMA_BLOCK();
+    }
     c_buf = c_buf == NSTAGE - 1 ? 0 : c_buf + 1;
     // The epilogue runs AFTER the barrier that ends the tile's last MFMA phase, i.e. in the first phase
     // of the next tile's first K-tile: group 0's overlaps group 1's last MFMA phase, group 1's (one
@@ -1285,13 +1319,13 @@ hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T, int EPI, int BM, int BN, int WM, int WN>
+template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
   static_assert(BM <= 160 && BN <= 256, "EpiLds layout");
   static bool attr_set = false;
   static int num_cu = 0;
-  auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN>;
+  auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN, PH2>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1328,7 +1362,9 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
 
 // Configurations.  0: simple 128x128 (4 waves)   1: simple 160x256 (8 waves 2x4)
 //                  2: simple 320x128 (8 waves 4x2)   3: simple 256x256 (8 waves 2x4)
-//                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production]
+//                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production; the residual and conv1
+//                     epilogues run the K loop in two long phases per K-tile, the others in four]
+//                  8: the same at 128x256 (experiment)   9: two long phases wherever they fit   10: four phases everywhere
 //                  5: deep-ring 64x64 (4 waves, 4-slot ring) for the few-hundred-row problems (head,
 //                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
 //                  7: one compute wave per SIMD, 160x256, one tile per block (gemm_q4_kernel; experiment)
@@ -1343,10 +1379,20 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 1: return launch_simple<T, EPI, 160, 256, 2, 4>(a, s);
     case 2: return launch_simple<T, EPI, 320, 128, 4, 2>(a, s);
     case 3: return launch_simple<T, EPI, 256, 256, 2, 4>(a, s);
-    case 4: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
+    case 4:  // production: two long phases per K-tile where the epilogue keeps no tile pending (residual, conv1)
+      if constexpr (EPI == EPI_RESID16 || EPI == EPI_PATCH16)
+        return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+      else
+        return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
+    case 10: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);  // four short phases for every epilogue (A/B, cycle stamps)
     case 5: return launch_deep<T, EPI, 64, 64, 2, 2>(a, s);
     case 6: return launch_simple<T, EPI, 64, 64, 2, 2>(a, s);
     case 8: return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);  // experiment: 64 x 64 wave tiles
+    case 9:  // two long phases per K-tile (epilogues without a pending tile / LayerNorm statistics)
+      if constexpr (EPI == EPI_RESID16 || EPI == EPI_PATCH16 || EPI == EPI_F32_BIAS)
+        return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+      else
+        return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     case 7:  // one compute wave per SIMD (experiment): residual / bias epilogues without LN statistics from LDS
       if constexpr (EPI == EPI_RESID16 || EPI == EPI_T16_BIAS || EPI == EPI_F32_BIAS)
         return launch_q4<T, EPI, 160, 256>(a, s);
@@ -1390,7 +1436,7 @@ bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts) {
   a.M = M; a.N = N; a.K = K;
   a.opts = opts;
   const int v = pick_variant(a);
-  return (v == 4 || v == 8) && K >= 3 * BK;
+  return (v == 4 || v == 8 || v == 9 || v == 10) && K >= 3 * BK;
 }
 
 bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,

@@ -27,7 +27,7 @@ def test_gemm(lib, cuda, dtype, m, n, k):
     _gemm_case(lib, cuda, dtype, m, n, k)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 132, 3072), (12800, 768, 128)])
 def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
     """Every tile configuration (csrc/gemm.hip) on ragged M/N edges."""
@@ -38,7 +38,7 @@ def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
         lib.oake_debug_set_gemm_variant(-1)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize('gelu', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 136, 512),
@@ -98,12 +98,16 @@ def test_gemm_layernorm_folded(lib, cuda, variant, gelu, dtype, m, n, k):
     torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize('variant', [-1, 10])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (2250, 768, 3072), (12800, 512, 256),
-                                   (333, 136, 512), (50, 768, 768)])
-def test_gemm_residual_epilogue(lib, cuda, dtype, m, n, k):
+                                   (333, 136, 512), (50, 768, 768), (41000, 768, 192), (25600, 768, 768)])
+def test_gemm_residual_epilogue(lib, cuda, dtype, m, n, k, variant):
     """x += A W^T + b in the 16-bit residual stream (out_proj / c_proj), ragged tiles included, plus the
-    per-slice row sums the persistent kernel leaves for the next GEMM's LayerNorm."""
+    per-slice row sums the persistent kernel leaves for the next GEMM's LayerNorm.  The last two shapes give
+    every persistent block several tiles with different bias blocks (771 / 480 tiles on 256 CUs; K = 192 is
+    the shortest K loop the kernel takes): the staging of a tile's epilogue constants must not overtake the
+    previous tile's epilogue."""
     g = torch.Generator(device='cpu').manual_seed(m + n + k)
     a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
     w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(dtype).to(cuda)
@@ -111,10 +115,14 @@ def test_gemm_residual_epilogue(lib, cuda, dtype, m, n, k):
     x0 = torch.randn(m, n, generator=g).to(dtype).to(cuda)
     x = x0.clone()
     part = torch.full((m, 16, 2), float('nan'), device=cuda)
-    rc = lib.oake_debug_gemm_resid16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(),
-                                     part.data_ptr(), m, n, k, DT[dtype], _stream())
-    assert rc == 0
-    torch.cuda.synchronize()
+    lib.oake_debug_set_gemm_variant(variant)  # -1: automatic (two long phases per K-tile); 10: four short phases
+    try:
+        rc = lib.oake_debug_gemm_resid16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(),
+                                         part.data_ptr(), m, n, k, DT[dtype], _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.oake_debug_set_gemm_variant(-1)
     ref = x0.float() + a.float() @ w.float().t() + bias
     tol = 4e-3 if dtype == torch.float16 else 3e-2
     torch.testing.assert_close(x.float(), ref, rtol=tol, atol=tol)

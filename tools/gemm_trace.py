@@ -8,7 +8,7 @@ lib = _lib.load()
 dev = torch.device('cuda:0')
 m, n, k = (int(v) for v in sys.argv[1:4])
 mode = sys.argv[4] if len(sys.argv) > 4 else 'bias'
-lib.oake_debug_set_gemm_variant(int(sys.argv[5]) if len(sys.argv) > 5 else 4)
+lib.oake_debug_set_gemm_variant(int(sys.argv[5]) if len(sys.argv) > 5 else 10)  # 10: four short phases (the stamped form)
 a = (torch.randn(m, k, device=dev) * 0.5).half(); w = (torch.randn(n, k, device=dev) * k ** -0.5).half()
 bias = torch.randn(n, device=dev)
 c = torch.empty(m, n, device=dev, dtype=torch.float32 if mode == 'f32' else torch.float16)
