@@ -1010,9 +1010,16 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
         }
       }
       if constexpr (PH2) {  // two long phases per K-tile: half of the pieces in each
-        static_assert(!PH2 || !LN, "the long-phase schedule serves the epilogues without LayerNorm statistics");
         OAKE_STAGE(0, Q2);
         OAKE_BAR();
+        if constexpr (LN) {  // (group 1's previous-tile epilogue ran in the first K-tile's last phase: one K-tile later)
+          if (d_kt == 1 && lane < RPW) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) f32x2* lds_f2w_t;
+            *(lds_f2w_t)(smem + NSTAGE * kStageBytes + EpiLds::kRowstat + (lw * RPW + lane) * 8) =
+                f32x2{st_rstd, st_shift};
+          }
+        }
         OAKE_STAGE(Q2, NPL);
       } else {
       OAKE_STAGE(0, Q1);  // flat K-tile g+2, a quarter of the pieces per phase
@@ -1381,6 +1388,11 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 3: return launch_simple<T, EPI, 256, 256, 2, 4>(a, s);
     case 4:  // production: two long phases per K-tile where the epilogue keeps no tile pending (residual, conv1)
       if constexpr (EPI == EPI_RESID16 || EPI == EPI_PATCH16)
+        return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+      // ... and for c_fc's epilogue (LayerNorm affine + QuickGELU): long phases + all stores at the tile end
+      // beat four phases + trickled stores there (+1.1 % on the bench, A/B of two builds in one session; for
+      // qkv's lighter epilogue the same switch is neutral: it keeps the trickled stores)
+      else if constexpr (EPI == EPI_T16_GELU_LN)
         return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
       else
         return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
