@@ -238,6 +238,8 @@ class ObjectsWork(_Work):
         self.ds = objects.COCODataset.__new__(objects.COCODataset)
         self.ds._grid, self.ds._expand_mode = v.grid, objects.ExpandMode.ADAPTIVE
         self._indices = objects.indices_min_wh
+        from oadp_amd.oake.base import _PinnedPool
+        self.pool = _PinnedPool()
         self.images = _synthetic_u8_images(a.batch, w, h, self.dev, seed=177 + self.rank)
         self.props = [torch.from_numpy(p) for p in _synthetic_proposals(a.batch, a.proposals, w, h, 99 + self.rank)]
         self.wh = torch.tensor([w, h])
@@ -260,7 +262,14 @@ class ObjectsWork(_Work):
             masks.append(ds._masks(fg, boxes))
             boxes_per_image.append(boxes)
         objs = v.crop_resize_normalize_batch(self.images, boxes_per_image, out_dtype=torch.float16)
-        masks = torch.cat(masks).to(self.dev, non_blocking=True).half()
+        m = torch.cat(masks).half()  # 0/1: exact in fp16; up through a pinned slot, as objects.Validator does
+        slot, buf = self.pool.acquire(m.numel(), m.dtype)
+        src = buf.view(m.shape)
+        src.copy_(m)
+        masks = src.to(self.dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pool.release_after(slot, ev)
         embs = [v(objs[i:i + mb], masks[i:i + mb], normalize=True, out_dtype=torch.float16)
                 for i in range(0, objs.shape[0], mb)]
         return torch.cat(embs)

@@ -1240,6 +1240,223 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 #undef OAKE_BAR
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Two workgroups per CU: half-width tiles (BM x 128), each workgroup = 4 compute waves (one per SIMD,
+// 80 x 64 wave tiles) + 2 DMA waves, 2-slot LDS ring (72 KB) + the EpiLds block, so that TWO
+// workgroups fit one CU (12 waves = 3 per SIMD, 168 registers).  Nothing synchronises the two: while
+// one runs its tile-end epilogue (VALU + stores, the matrix pipe idle in a lone workgroup) the other is
+// somewhere in its K loop — the overlap the ping-pong kernel's lock-stepped groups cannot have, because
+// both of its groups reach the tile end together.  The price: 1.38x the LDS-DMA bytes per FLOP
+// ((160 + 128) vs (160 + 256) rows per K-tile for half the columns).
+//   per K-tile:   BAR | 18 fragment reads | 40 MFMAs            (compute waves)
+//                 BAR | issue K-tile g+1 into the other slot | vmcnt(0)   (DMA waves)
+// The barrier of K-tile g publishes K-tile g (the DMA waves waited for it) and frees the slot of K-tile
+// g-1 (every compute wave has read it).  At a tile's first K-tile the DMA waves also stage that tile's
+// bias / colsum / row statistics into EpiLds: every compute wave is past the previous tile's epilogue.
+template <typename T, int EPI, int BM, int BN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_duo_kernel(
+    const T* __restrict__ A, const T* __restrict__ W, int M, int N, int K, EpiParams ep, TileMap tmap) {
+  typedef typename T16<T>::vec8 vec8;
+  constexpr bool PAIRED = EpiTraits<EPI>::kPaired;
+  constexpr int WM = 2, WN = 2, NW = WM * WN, NL = 4;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int kATileBytes = BM * kRowBytes;
+  constexpr int kStageBytes = (BM + BN) * kRowBytes;
+  constexpr int NINST = (BM + BN) / 8;
+  static_assert(NINST % NL == 0 && (BM / 8) % NL == 0, "pieces split evenly over the DMA waves");
+  constexpr int NPL = NINST / NL;
+  constexpr int kAPieces = BM / 8 / NL;
+  static_assert(TM % 16 == 0 && TN % 32 == 0, "tile shape");
+  constexpr int NSTAGE = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nx = 8;
+  const int xcd = blockIdx.x % nx, xslot = blockIdx.x / nx;
+  const int per_xcd = gridDim.x / nx;
+  const int q = tmap.nwg / nx, r = tmap.nwg % nx;
+  const int xb = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int xc = xcd < r ? q + 1 : q;
+  const int my_tiles = xslot < xc ? (xc - xslot + per_xcd - 1) / per_xcd : 0;
+  if (my_tiles == 0) return;
+  const int nk = K / BK;
+  const int total = my_tiles * nk;
+  char* const elds_w = smem + NSTAGE * kStageBytes;
+
+#define OAKE_PIN() __builtin_amdgcn_sched_barrier(0)
+#define OAKE_BAR()                   \
+  do {                               \
+    OAKE_PIN();                      \
+    __builtin_amdgcn_s_barrier();    \
+    OAKE_PIN();                      \
+  } while (0)
+
+  if (wid >= NW) {
+    // ================= DMA wave =================
+    const int lw = wid - NW;
+    const char* src[NPL];
+    auto set_src = [&](int tile_i) {
+      int m0, n0;
+      tile_origin(tmap, xb + xslot + tile_i * per_xcd, BM, BN, m0, n0);
+#pragma unroll
+      for (int j = 0; j < NPL; ++j)
+        src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane, ep.patch_S,
+                                              ep.patch_P, ep.patch_G);
+    };
+    int s_kt = 0, s_tile = 0;  // producer cursor: K-tile s_kt of tile s_tile goes to slot (flat index) & 1
+    int d_kt = 0, d_tile = 0;  // the K-tile the compute waves work on
+#define OAKE_DUO_STAGE(buf_)                                                                       \
+  do {                                                                                           \
+    char* _base = smem + (buf_) * kStageBytes;                                                   \
+    const size_t _koff = (size_t)s_kt * (BK * 2);                                                \
+    const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P) : _koff;    \
+    _Pragma("unroll") for (int _j = 0; _j < NPL; ++_j)                                           \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
+                                         (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0);  \
+    if (++s_kt == nk) {                                                                          \
+      s_kt = 0;                                                                                  \
+      if (++s_tile < my_tiles) set_src(s_tile);                                                  \
+    }                                                                                            \
+  } while (0)
+    constexpr bool LN = EpiTraits<EPI>::kLn;
+    constexpr int RPW = BM / NL;  // rows per DMA wave: lanes take row `lane` and, below RPW - 64, row 64 + lane
+    static_assert(RPW <= 128, "two rows per lane at most");
+    set_src(0);
+    OAKE_DUO_STAGE(0);
+    for (int g = 0; g < total; ++g) {
+      float st_rstd[2] = {0.f, 0.f}, st_shift[2] = {0.f, 0.f};
+      if constexpr (LN) {
+        if (d_kt == 0) {
+          int _m0, _n0;
+          tile_origin(tmap, xb + xslot + d_tile * per_xcd, BM, BN, _m0, _n0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (64 * h + lane < RPW) {
+              int _m = _m0 + lw * RPW + 64 * h + lane;
+              _m = _m < M ? _m : M - 1;
+              const float4* _p = reinterpret_cast<const float4*>(ep.rowpart_in + (size_t)_m * kRowParts);
+              float4 _v[kRowParts / 2];
+#pragma unroll
+              for (int i = 0; i < kRowParts / 2; ++i)
+                _v[i] = 2 * i < ep.nparts ? _p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+              float _s1 = 0.f, _s2 = 0.f;
+#pragma unroll
+              for (int i = 0; i < kRowParts / 2; ++i) {
+                _s1 += _v[i].x;
+                _s2 += _v[i].y;
+                if (2 * i + 1 < ep.nparts) {
+                  _s1 += _v[i].z;
+                  _s2 += _v[i].w;
+                }
+              }
+              const float _mean = _s1 * ep.inv_k;
+              const float _var = fmaxf(_s2 * ep.inv_k - _mean * _mean, 0.f);
+              st_rstd[h] = rsqrtf(_var + 1e-5f);
+              st_shift[h] = -_mean * st_rstd[h];
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0), lgkmcnt(0): K-tile g (and the EpiLds block) landed
+      OAKE_BAR();  // publishes K-tile g; K-tile g-1's slot and, at a tile's first K-tile, EpiLds are free
+      if (g + 1 < total) OAKE_DUO_STAGE((g + 1) & 1);
+      if (d_kt == 0) {
+        int _m0, _n0;
+        tile_origin(tmap, xb + xslot + d_tile * per_xcd, BM, BN, _m0, _n0);
+        int _n = _n0 + 4 * lane;
+        _n = _n + 4 <= N ? _n : N - 4;
+        if (lane < BN / 4) {
+          if (lw == 0 && ep.bias != nullptr && EPI != EPI_PATCH && EPI != EPI_PATCH16)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.bias + _n), (lds_ptr_t)(elds_w + EpiLds::kBias), 16, 0, 0);
+          if (LN && lw == 1)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.colsum + _n), (lds_ptr_t)(elds_w + EpiLds::kColsum), 16, 0, 0);
+        }
+        if constexpr (LN) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef __attribute__((address_space(3))) f32x2* lds_f2w_t;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (64 * h + lane < RPW)
+              *(lds_f2w_t)(elds_w + EpiLds::kRowstat + (lw * RPW + 64 * h + lane) * 8) =
+                  f32x2{st_rstd[h], st_shift[h]};
+        }
+      }
+      if (++d_kt == nk) {
+        d_kt = 0;
+        ++d_tile;
+      }
+    }
+#undef OAKE_DUO_STAGE
+    return;
+  }
+
+  // ================= compute wave =================
+  const int wm = wid / WN, wn = wid % WN;
+  const int frow = lane & 15;
+  const int fg = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  const int a_base = (wm * TM + frow) * kRowBytes;
+  const int b_base = kATileBytes + (wn * TN + frow) * kRowBytes;
+  const int koff0 = ((0 * 4 + fg) ^ fsw) << 4;
+  const int koff1 = ((1 * 4 + fg) ^ fsw) << 4;
+  const char* elds = elds_w;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c_buf = 0, c_kt = 0, c_tile = 0;
+  for (int g = 0; g < total; ++g) {
+    OAKE_BAR();
+    {
+      vec8 af[MI], bf[NI], af1[MI], bf1[NI];
+      const char* _st = smem + c_buf * kStageBytes;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) bf[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af1[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff1);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) bf1[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf1[ni], af1[mi], acc[mi][ni]);
+    }
+    c_buf ^= 1;
+    if (++c_kt == nk) {
+      c_kt = 0;
+      int m0, n0;
+      tile_origin(tmap, xb + xslot + c_tile * per_xcd, BM, BN, m0, n0);
+      ++c_tile;
+      OAKE_PIN();
+      // lane coordinates re-derived behind an opaque asm: hipcc would otherwise keep every epilogue address
+      // in a VGPR across the K loop
+      int etid = tid;
+      asm volatile("" : "+v"(etid));
+      const int efrow = etid & 15, efg = (etid & 63) >> 4;
+      tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + wm * TM + efrow, n0 + wn * TN, efg, M, N, ep, false,
+                                        m0 + BM <= M && n0 + BN <= N, elds, wn * TN, wm * TM + efrow);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#undef OAKE_PIN
+#undef OAKE_BAR
+}
+
 // ---- host side ------------------------------------------------------------------------------
 TileMap make_tilemap(const GemmArgs& a, int BM, int BN) {
   TileMap tmap;
@@ -1249,7 +1466,8 @@ TileMap make_tilemap(const GemmArgs& a, int BM, int BN) {
   int pn = 768 / BN;  // ~768-column panels: a W panel of K=768 is ~1.2 MB of an XCD's 4 MiB L2
   pn = pn < 1 ? 1 : pn;
   tmap.by_m = 0;
-  const int panel = a.opts ? a.opts->gemm_panel : 0;
+  int panel = a.opts ? a.opts->gemm_panel : 0;
+  if (panel >= 1000) panel -= 1000;  // (>= 1000: launch_duo's one-workgroup-per-CU switch)
   if (panel > 0) pn = panel;
   if (panel < 0) {
     tmap.by_m = 1;
@@ -1367,6 +1585,47 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <typename T, int EPI, int BM, int BN>
+hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
+  constexpr int lds = 2 * (BM + BN) * kRowBytes + EpiLds::kBytes;
+  static_assert(BM <= 160 && BN <= 256 && 2 * lds <= 160 * 1024, "two workgroups per CU");
+  static bool attr_set = false;
+  static int num_cu = 0;
+  auto kern = gemm_duo_kernel<T, EPI, BM, BN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+    num_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  if (a.K < 3 * BK) {  // (as launch_pp: the callers' row-statistics hand-off assumes the same threshold)
+    if (a.patch_S != 0) return hipErrorInvalidValue;
+    return launch_simple<T, EPI, BM, BN, 2, 2>(a, s);
+  }
+  const TileMap tmap = make_tilemap(a, BM, BN);
+  const int per_cu = a.opts && a.opts->gemm_panel >= 1000 ? 1 : 2;  // (1000: one workgroup per CU, the A/B of the overlap)
+  int grid = (per_cu * num_cu / 8) * 8;
+  if (grid < 8) grid = 8;
+  const int need = ((tmap.nwg + 7) / 8) * 8;
+  if (grid > need) grid = need;
+  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum,
+               reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
+               a.nparts, 1.0f / (float)a.K, 0, 0, 0};
+  if (a.patch_S != 0) {
+    if (EPI != EPI_PATCH16 && EPI != EPI_PATCH) return hipErrorInvalidValue;
+    ep.patch_S = a.patch_S; ep.patch_P = a.patch_P; ep.patch_G = a.patch_G;
+  }
+  OAKE_LAUNCH(kern, dim3(grid), dim3(512), lds, s, reinterpret_cast<const T*>(a.A),
+              reinterpret_cast<const T*>(a.W), a.M, a.N, a.K, ep, tmap);
+  return hipGetLastError();
+}
+
 // Configurations.  0: simple 128x128 (4 waves)   1: simple 160x256 (8 waves 2x4)
 //                  2: simple 320x128 (8 waves 4x2)   3: simple 256x256 (8 waves 2x4)
 //                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production; the residual and conv1
@@ -1375,10 +1634,12 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
 //                  5: deep-ring 64x64 (4 waves, 4-slot ring) for the few-hundred-row problems (head,
 //                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
 //                  7: one compute wave per SIMD, 160x256, one tile per block (gemm_q4_kernel; experiment)
+//                 11: two workgroups per CU, 160x128 tiles (gemm_duo_kernel; experiment)
 template <typename T, int EPI>
 hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
   if constexpr (EpiTraits<EPI>::kNone || EpiTraits<EPI>::kRaw) {  // measurement epilogues: persistent kernels only
     if (variant == 8) return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);
+    if (variant == 11) return launch_duo<T, EPI, 160, 128>(a, s);
     return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
   } else
   switch (variant) {
@@ -1394,6 +1655,11 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
       // qkv's lighter epilogue the same switch is neutral: it keeps the trickled stores)
       else if constexpr (EPI == EPI_T16_GELU_LN)
         return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+      else
+        return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
+    case 11:  // two workgroups per CU, 160x128 tiles (the 16-bit epilogues that fit 128 registers)
+      if constexpr (EpiTraits<EPI>::kPaired && !EpiTraits<EPI>::kLn && EPI != EPI_RESID16)
+        return launch_duo<T, EPI, 160, 128>(a, s);
       else
         return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     case 10: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);  // four short phases for every epilogue (A/B, cycle stamps)
@@ -1448,7 +1714,7 @@ bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts) {
   a.M = M; a.N = N; a.K = K;
   a.opts = opts;
   const int v = pick_variant(a);
-  return (v == 4 || v == 8 || v == 9 || v == 10) && K >= 3 * BK;
+  return (v == 4 || v == 8 || v == 9 || v == 10 || v == 11) && K >= 3 * BK;
 }
 
 bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,

@@ -193,26 +193,47 @@ class _HostCopy:
 
 
 class _PinnedPool:
-    """Pinned host buffers for asynchronous device -> host copies; a buffer is handed out to one copy at a
-    time and returns when that copy's result has been taken (a new one is allocated if all are in flight)."""
+    """Pinned host buffers for asynchronous copies in either direction; a buffer is handed out to one copy
+    at a time and returns when that copy's result has been taken (device -> host: ``release``) or when the
+    copy has run (host -> device: ``release_after`` an event); a new one is allocated if all are in flight."""
 
     def __init__(self) -> None:
         self._bufs: list[torch.Tensor] = []
         self._busy: list[bool] = []
+        self._events: dict[int, Any] = {}
+
+    @staticmethod
+    def _alloc(nbytes: int) -> torch.Tensor:
+        return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+
+    def release_after(self, slot: int, event: Any) -> None:
+        self._events[slot] = event
 
     def acquire(self, numel: int, dtype: torch.dtype) -> tuple[int, torch.Tensor]:
-        for i, (buf, busy) in enumerate(zip(self._bufs, self._busy)):
-            if not busy and buf.dtype == dtype and buf.numel() >= numel:
-                self._busy[i] = True
-                return i, buf
-        for i, busy in enumerate(self._busy):  # a free buffer of the wrong size / type: replace it
-            if not busy:
-                self._bufs[i] = torch.empty(max(numel, 1), dtype=dtype, pin_memory=True)
-                self._busy[i] = True
-                return i, self._bufs[i]
-        self._bufs.append(torch.empty(max(numel, 1), dtype=dtype, pin_memory=True))
-        self._busy.append(True)
-        return len(self._bufs) - 1, self._bufs[-1]
+        """(slot, pinned 1-D tensor of >= numel elements of dtype).  Buffers are untyped bytes with
+        power-of-two capacities, so requests of different types and slowly varying sizes (images, masks,
+        embeddings of successive flushes) reuse them instead of re-pinning memory."""
+        for slot in [k for k, ev in self._events.items() if ev.query()]:
+            del self._events[slot]
+            self._busy[slot] = False
+        item = torch.empty(0, dtype=dtype).element_size()
+        need = max(numel, 1) * item
+        free = [i for i, busy in enumerate(self._busy) if not busy]
+        fit = [i for i in free if self._bufs[i].numel() >= need]
+        if fit:
+            i = min(fit, key=lambda k: self._bufs[k].numel())
+        else:
+            cap = 1 << max(need - 1, 4095).bit_length()
+            buf = self._alloc(cap)
+            if free:  # too small: replace the largest free one
+                i = max(free, key=lambda k: self._bufs[k].numel())
+                self._bufs[i] = buf
+            else:
+                self._bufs.append(buf)
+                self._busy.append(False)
+                i = len(self._bufs) - 1
+        self._busy[i] = True
+        return i, self._bufs[i][:need].view(dtype)
 
     def release(self, slot: int) -> None:
         self._busy[slot] = False
@@ -375,9 +396,26 @@ class BaseValidator(ABC, Generic[T]):
                     import io
                     img = image_to_u8(PIL.Image.open(io.BytesIO(ts[i].numpy().tobytes()))).to(self._device)
                 out[i] = img
-        for i, t in enumerate(ts):
-            if out[i] is None:
-                out[i] = t.to(self._device, non_blocking=True)
+        raw = [i for i in range(len(ts)) if out[i] is None]
+        if raw and self._device.type == 'cuda':
+            # all raw uint8 images of the flush in ONE copy through a pinned slot (each at a 256-byte
+            # boundary), instead of one stream-ordered copy from pageable memory per image
+            offs, total = [], 0
+            for i in raw:
+                offs.append(total)
+                total += -(-ts[i].numel() // 256) * 256
+            slot, buf = self._host_pool.acquire(total, torch.uint8)
+            for i, o in zip(raw, offs):
+                buf[o:o + ts[i].numel()].view(ts[i].shape).copy_(ts[i])
+            dev = buf[:total].to(self._device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._host_pool.release_after(slot, ev)
+            for i, o in zip(raw, offs):
+                out[i] = dev[o:o + ts[i].numel()].view(ts[i].shape)
+        else:
+            for i in raw:
+                out[i] = ts[i].to(self._device)
         return out
 
     def _to_host(self, t: torch.Tensor) -> '_HostCopy':
@@ -393,6 +431,22 @@ class BaseValidator(ABC, Generic[T]):
         ev = torch.cuda.Event()
         ev.record()
         return _HostCopy(dst, ev, self._host_pool, slot)
+
+    def _to_device(self, t: torch.Tensor) -> torch.Tensor:
+        """Host tensor -> device without blocking the host: a copy from pageable memory waits for the
+        stream it is queued on (here: for the crops of this flush and whatever that lane still runs), so
+        the tensor goes through a pinned slot that is taken back when the copy has run."""
+        if self._device.type != 'cuda' or t.is_cuda or t.numel() == 0:
+            return t.to(self._device)
+        n = t.numel()
+        slot, buf = self._host_pool.acquire(n, t.dtype)
+        src = buf[:n].view(t.shape)
+        src.copy_(t)
+        out = src.to(self._device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._host_pool.release_after(slot, ev)
+        return out
 
     def _submit(self, batches: list[T], results: list) -> None:
         assert self._writer is not None

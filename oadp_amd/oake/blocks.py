@@ -151,7 +151,7 @@ class Validator(BaseValidator[Batch]):
                 if got != counts:
                     raise RuntimeError(f'{got} blocks cut, {counts} expected from the datasets\' bboxes')
         else:
-            blocks = torch.cat([b.blocks for b in batches]).to(self._device, non_blocking=True)
+            blocks = self._to_device(torch.cat([b.blocks for b in batches]))
             counts = [b.blocks.shape[0] for b in batches]
         host = self._to_host(self._model.encode_image(blocks, normalize=True, out_dtype=torch.float16))
         bboxes = [b.bboxes.half() for b in batches]

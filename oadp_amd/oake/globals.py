@@ -49,7 +49,7 @@ class Validator(BaseValidator[Batch]):
                 decoded, [[(0, 0, im.shape[1], im.shape[0])] for im in decoded], squash=squash,
                 out_dtype=torch.float16)
         else:
-            images = torch.stack([b.image for b in batches]).to(self._device, non_blocking=True)
+            images = self._to_device(torch.stack([b.image for b in batches]))
         host = self._to_host(self._model.encode_image(images, normalize=True, out_dtype=torch.float16))
         n = len(batches)
 

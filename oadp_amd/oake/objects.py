@@ -205,13 +205,15 @@ class Validator(BaseValidator[Batch]):
                 out_dtype=torch.float16)
         else:
             objects = torch.cat([b.objects for b in batches])
-        masks = torch.cat([b.masks for b in batches])
+        # the 0/1 masks of the whole flush go up once, as fp16 through a pinned slot (exact; the native
+        # attention bias is -100 * mask either way)
+        masks = self._to_device(torch.cat([b.masks for b in batches]).half())
+        if not objects.is_cuda:
+            objects = self._to_device(objects)
         embs = []
         for i in range(math.ceil(objects.shape[0] / self._mini_batch_size)):
             sl = slice(i * self._mini_batch_size, (i + 1) * self._mini_batch_size)
-            o = objects[sl].to(self._device, non_blocking=True)
-            m = masks[sl].to(self._device, non_blocking=True)
-            embs.append(self._model.visual(o, m, normalize=True, out_dtype=torch.float16))
+            embs.append(self._model.visual(objects[sl], masks[sl], normalize=True, out_dtype=torch.float16))
         on_gpu = bool(embs) and embs[0].is_cuda
         # one device -> host copy per flush, left in flight while the next flush is prepared (base._flush)
         host = self._to_host(torch.cat(embs)) if embs else None

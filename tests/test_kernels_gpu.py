@@ -27,7 +27,7 @@ def test_gemm(lib, cuda, dtype, m, n, k):
     _gemm_case(lib, cuda, dtype, m, n, k)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 132, 3072), (12800, 768, 128)])
 def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
     """Every tile configuration (csrc/gemm.hip) on ragged M/N edges."""
@@ -38,7 +38,7 @@ def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
         lib.oake_debug_set_gemm_variant(-1)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize('gelu', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 136, 512),

@@ -300,3 +300,42 @@ def test_one_flush_stays_in_flight(coco, tmp_path):
     globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, ref), batch_size=2, device='cpu').run()
     for p in out.iterdir():
         assert torch.equal(torch.load(p, 'cpu'), torch.load(ref / p.name, 'cpu'))
+
+
+def test_pinned_pool_reuses_byte_buffers(monkeypatch):
+    """The staging pool behind the asynchronous copies: untyped byte buffers, one owner at a time, taken
+    back on ``release`` (device -> host) or when the copy's event has completed (host -> device)."""
+    from oadp_amd.oake.base import _PinnedPool
+    allocs = []
+
+    def alloc(nbytes):
+        allocs.append(nbytes)
+        return torch.empty(nbytes, dtype=torch.uint8)
+
+    monkeypatch.setattr(_PinnedPool, '_alloc', staticmethod(alloc))
+
+    class Ev:
+        def __init__(self): self.done = False
+        def query(self): return self.done
+
+    pool = _PinnedPool()
+    s0, a = pool.acquire(1000, torch.float16)
+    assert a.dtype == torch.float16 and a.numel() == 1000 and allocs == [4096]
+    s1, b = pool.acquire(3 * 640 * 480, torch.uint8)
+    assert s1 != s0 and b.numel() == 3 * 640 * 480 and allocs[-1] == 1 << 20
+    a.fill_(1)
+    b.fill_(2)
+    assert (a == 1).all()  # separate storage
+    ev = Ev()
+    pool.release_after(s1, ev)
+    s2, c = pool.acquire(500_000, torch.uint8)  # s1's copy has not run: a third buffer
+    assert s2 not in (s0, s1) and len(allocs) == 3
+    ev.done = True
+    pool.release(s0)
+    s3, d = pool.acquire(100_000, torch.float32)  # s1 is free again and large enough: no allocation
+    assert s3 == s1 and d.dtype == torch.float32 and d.numel() == 100_000 and len(allocs) == 3
+    s4, e = pool.acquire(600, torch.float16)  # smallest fitting free buffer
+    assert s4 == s0 and len(allocs) == 3
+    pool.release(s4)
+    s5, f = pool.acquire(1 << 22, torch.uint8)  # nothing free fits: the free buffer is replaced by a larger one
+    assert s5 == s0 and allocs[-1] == 1 << 22 and f.numel() == 1 << 22
