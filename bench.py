@@ -307,6 +307,46 @@ class ObjectsWork(_Work):
                           f'{self.args.proposals} proposals per image'}
 
 
+
+def _sustained_mfma(dev, seconds: float = 1.2) -> dict:
+    """What matrix rate does THIS board sustain under its power cap?  A register-only MFMA stream on every
+    SIMD (oake_debug_mfma_probe: no LDS, no memory) with all-zero operands and with N(0, 0.25) f16 operands —
+    the same instruction stream, only the bits differ.  The data-sheet peak (2.5 PFLOP/s at 2.4 GHz) is
+    reached with operands that do not toggle; with the operand statistics of the encoder the board is at its
+    power cap with nothing but MFMAs running.  Measured live, after the timed region."""
+    import ctypes as C
+    import torch
+    from oadp_amd import _lib
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sink = torch.zeros(1, device=dev)
+    g = torch.Generator(device='cpu').manual_seed(7)
+    out = {}
+    for name, frags in (('zeros', torch.zeros(9 * 64 * 8)), ('random', torch.randn(9 * 64 * 8, generator=g) * 0.5)):
+        f = frags.half().to(dev)
+        flop = C.c_double(0)
+        iters = 20000
+
+        def run(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                rc = lib.oake_debug_mfma_probe(f.data_ptr(), sink.data_ptr(), iters, C.byref(flop), stream)
+                assert rc == 0, rc
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3
+
+        run(2)
+        spent, last = 0.0, (1.0, 1)
+        while spent < seconds:  # clocks settle within a few hundred ms: the rate of the last batch is reported
+            dt = run(20)
+            spent += dt
+            last = (dt, 20)
+        out[name] = round(flop.value * last[1] / last[0] / 1e12, 1)
+    return out
+
+
 WORKS = {'globals': GlobalsWork, 'blocks': BlocksWork, 'objects': ObjectsWork}
 DEFAULT_BATCH = {'globals': 256, 'blocks': 64, 'objects': 8}
 DEFAULT_MAX_BATCH = {'globals': None, 'blocks': 512, 'objects': 512}
@@ -496,6 +536,15 @@ def main() -> int:
                             roofline['avg_launch_us_rocprofv3'] = round(float(row['AverageNs']) / 1e3, 2)
                             roofline['rocprofv3_summary'] = {'file': os.path.relpath(spath, ROOT), 'live': False,
                                                              'session': tj.get('_session', 'unknown')}
+        if world == 1 and args.dtype == 'f16':
+            sus = _sustained_mfma(dev)
+            roofline['sustained'] = {
+                'zero_operands': sus['zeros'], 'random_operands': sus['random'], 'unit': 'TFLOP/s',
+                'frac_of_random': round(achieved / sus['random'], 4), 'live': True,
+                'what': 'register-only v_mfma_f32_16x16x32_f16 stream on every SIMD (oake_debug_mfma_probe), '
+                        'all-zero vs N(0,0.25) f16 operands, measured after the timed region: the rate the '
+                        'board sustains under its power cap; `peak` above is the data-sheet number',
+            }
         tot_ms = sum(p['total_ms'] for p in prof)
         kernels = {p['name']: {'ms_per_step': round(p['total_ms'] / n_prof, 4),
                                'share': round(p['total_ms'] / tot_ms, 4),
@@ -533,6 +582,8 @@ def main() -> int:
                        'backend': backend if dist else None, 'hip_streams': n_lanes},
             'crops_per_sec': None if DRY_PLUMBING else round(crops_per_s, 1),
             'mfma_roofline_frac_e2e': None if DRY_PLUMBING else round(crops_per_s / world * flop_crop / PEAK_MFMA_DENSE, 4),
+            'mfma_sustained_frac_e2e': (round(crops_per_s * flop_crop / (roofline['sustained']['random_operands'] * 1e12), 4)
+                                        if roofline and roofline.get('sustained') else None),
             'flop_per_crop': {'model': work.flop_model_per_crop, 'executed': flop_crop},
             'one_lane_images_per_sec': one_lane,
             'roofline': roofline,

@@ -311,6 +311,11 @@ OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, 
                          int dtype16, void* stream);
 /* Raw ds_read_b64_tr_b16 semantics probe: in = 256 uint16, out = 64 lanes x 4 uint16. */
 OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
+/* Measurement: a register-only MFMA stream (two waves per SIMD on every CU, `iters` x 20
+ * v_mfma_f32_16x16x32_f16 per wave, no LDS or memory traffic) on the 9 x 64 x 8 f16 operand fragments at
+ * d_frags16; *flop (host, may be NULL) receives the FLOPs of the launch.  Timed by the caller, it gives the
+ * matrix rate the board sustains under its power cap for that operand data (bench.py `roofline.sustained`). */
+OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream);
 /* Attention variant bits: 1 = ds_read_b64_tr_b16 V fragments (else 16-bit LDS gathers),
  * 2 = 32 queries per wave (else 64), 4 = sequences longer than 64 keys share K / V through LDS between
  * the four waves of a block, 8 = objects mode: the object token's attention rides on an idle wave

@@ -70,6 +70,7 @@ SIGNATURES = {
     'oake_debug_layernorm': (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),
     'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
+    'oake_debug_mfma_probe': (_I, [_VP, _VP, C.c_int, C.POINTER(C.c_double), _VP]),
     'oake_debug_set_attention_variant': (_I, [_I]),
     'oake_debug_set_gemm_variant': (_I, [_I]),
     'oake_debug_gemm_resid16': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),

@@ -1622,6 +1622,11 @@ int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
   return dbg(launch_tr_read_probe(d_in, d_out, reinterpret_cast<hipStream_t>(stream)));
 }
 
+int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream) {
+  if (d_frags16 == nullptr || d_sink == nullptr || iters < 1) return OAKE_ERR_INVALID;
+  return dbg(launch_mfma_probe(d_frags16, d_sink, iters, flop, reinterpret_cast<hipStream_t>(stream)));
+}
+
 int oake_debug_set_gemm_variant(int variant) {
   t_debug_opts.gemm_variant = variant < 0 ? -1 : variant;
   return OAKE_OK;

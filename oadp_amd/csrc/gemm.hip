@@ -1457,6 +1457,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef OAKE_BAR
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-only MFMA stream (measurement: bench.py's `roofline.sustained`, tools/ubench/mfma_power.hip):
+// every SIMD runs two waves of back-to-back v_mfma_f32_16x16x32_f16 on the production 5 x 4 wave tile
+// with the operand fragments the caller supplies — no LDS, no memory traffic.  What it measures is the
+// matrix rate the board sustains under its power cap for that operand DATA (zeros: the 2.4 PFLOP/s of the
+// data sheet at 2.39 GHz / 0.75 kW; N(0, 0.25) halves: 1.9 PFLOP/s at 1.94 GHz / 1.33 kW, capped).
+__global__ __launch_bounds__(512) void mfma_probe_kernel(const f16x8* __restrict__ frags, float* sink,
+                                                         int iters) {
+  const int lane = threadIdx.x & 63;
+  f16x8 af[5], bf[4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) af[i] = frags[i * 64 + lane];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bf[j] = frags[(5 + j) * 64 + lane];
+  f32x4 acc[5][4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (t == 12345.678f) sink[0] = t;  // (keeps the MFMAs alive; never true for the data the probe is given)
+}
+
 // ---- host side ------------------------------------------------------------------------------
 TileMap make_tilemap(const GemmArgs& a, int BM, int BN) {
   TileMap tmap;
@@ -1724,6 +1758,19 @@ bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, 
   return stride == patch && padding == 0 && image % patch == 0 && patch % 8 == 0 && BK % patch == 0 &&
          (patch * patch) % BK == 0 && image % 8 == 0 && K == 3 * patch * patch &&
          gemm_uses_persistent(M, N, K, opts);
+}
+
+hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return e;
+  const int cus = prop.multiProcessorCount;
+  OAKE_LAUNCH(mfma_probe_kernel, dim3(cus), dim3(512), 0, s, reinterpret_cast<const f16x8*>(d_frags), d_sink,
+              iters);
+  if (flop != nullptr) *flop = (double)cus * 8 * 20 * 16384.0 * (double)iters;
+  return hipGetLastError();
 }
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {

@@ -200,5 +200,7 @@ hipError_t launch_jpeg_reconstruct(const JpegFrame& frame, const int16_t* d_coef
                                    uint8_t* d_out_hwc, hipStream_t s);
 
 hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s);
+// register-only MFMA stream on every SIMD (gemm.hip): d_frags = 9 x 64 x 8 halves, *flop = work of the launch
+hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s);
 
 }  // namespace oake

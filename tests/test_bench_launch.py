@@ -59,3 +59,7 @@ def test_modes_produce_a_contract_line(mode, extra):
     assert line['unit'] == 'images/sec' and line['crops_per_sec'] > line['value']
     rf = line['roofline']
     assert rf['bound'] == 'mfma' and 0 < rf['frac'] < 1 and rf['kernel'].startswith('gemm')
+    # the live power-cap probe: zero operands reach the data-sheet rate, random ones are capped below it
+    sus = rf['sustained']
+    assert sus['live'] and 1000 < sus['random_operands'] <= sus['zero_operands'] * 1.02 < 2700
+    assert 0 < line['mfma_sustained_frac_e2e'] < 1

@@ -209,3 +209,17 @@ def test_tr_read_semantics(lib, cuda):
     lanes = torch.arange(64)
     exp = torch.stack([64 * (lanes // 16) + 16 * j + (lanes % 16) for j in range(4)], dim=1)
     assert torch.equal(got, exp.to(torch.int16)), f'tr-read mapping differs:\n{got}'
+
+
+def test_mfma_probe_counts_its_work(lib, cuda):
+    """oake_debug_mfma_probe (bench.py's power-cap probe): runs, reports CUs x 8 waves x 20 MFMAs x 16384 FLOP
+    per iteration, and leaves its sink alone."""
+    import ctypes as C
+    frags = (torch.randn(9 * 64 * 8) * 0.5).half().to(cuda)
+    sink = torch.zeros(1, device=cuda)
+    flop = C.c_double(0)
+    assert lib.oake_debug_mfma_probe(frags.data_ptr(), sink.data_ptr(), 100, C.byref(flop), _stream()) == 0
+    torch.cuda.synchronize()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert flop.value == cus * 8 * 20 * 16384.0 * 100 and sink.item() == 0.0
+    assert lib.oake_debug_mfma_probe(0, sink.data_ptr(), 100, None, _stream()) != 0
