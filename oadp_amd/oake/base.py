@@ -321,6 +321,9 @@ class Counters:
 
 def gather_counters(counters: Counters, device) -> list[list[float]]:
     """Rank-0 throughput report: one all_gather of 4 x f64 per rank (RCCL on GPU, gloo on CPU)."""
+    if (torch.distributed.is_available() and torch.distributed.is_initialized()
+            and torch.distributed.get_backend() == 'gloo'):
+        device = 'cpu'
     t = counters.tensor(device)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         out = [torch.zeros_like(t) for _ in range(torch.distributed.get_world_size())]
@@ -334,7 +337,7 @@ class BaseValidator(ABC, Generic[T]):
     def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
                  batch_size: int = 256, device: torch.device | str | None = None,
                  writer_threads: int = 4, decode_threads: int = 16, prefetch: int = 512,
-                 streams: int = 2, **kwargs) -> None:
+                 streams: int = 2, host_threads: int = 8, **kwargs) -> None:
         if kwargs:  # a misspelled option must not vanish silently
             raise TypeError(f'{type(self).__name__}: unknown option(s) {sorted(kwargs)}')
         self.name = name
@@ -348,6 +351,12 @@ class BaseValidator(ABC, Generic[T]):
         self._writer_threads = writer_threads
         self._decode_threads = decode_threads
         self._prefetch = prefetch
+        # torch's intra-op pool for the sweep: the host side of a flush is hundreds of tiny tensor ops per
+        # image (.half(), clone, cat of a few KB), and with the default — one OpenMP thread per core — each
+        # of them wakes the whole pool: on a 256-thread host the blocks sweep ran at 880 images/s against
+        # 3 250 with the pool capped (tools/sweep_ranks.py; torchrun sets OMP_NUM_THREADS=1 for the same
+        # reason).  0 leaves torch's setting alone.
+        self._host_threads = host_threads
         self._writer: AsyncWriter | None = None
         self._inflight: tuple[list, Any] | None = None   # the flush whose results are still on the GPU
         self._host_pool = _PinnedPool()
@@ -493,6 +502,9 @@ class BaseValidator(ABC, Generic[T]):
         t0 = time.perf_counter()
         pending: list[T] = []
         crops = 0
+        torch_threads = torch.get_num_threads()
+        if 0 < self._host_threads < torch_threads:  # (before the worker threads run their first tensor op)
+            torch.set_num_threads(self._host_threads)
         self._writer = AsyncWriter(self._writer_threads)
         try:
             self._run_loop(pending, crops)
@@ -502,6 +514,8 @@ class BaseValidator(ABC, Generic[T]):
                 writer.close()  # every file of this split is on disk (or the error is raised) here
             finally:
                 self.counters.bytes += writer.bytes
+                if torch.get_num_threads() != torch_threads:
+                    torch.set_num_threads(torch_threads)
         if self._device.type == 'cuda':
             torch.cuda.synchronize(self._device)
         self.counters.seconds += time.perf_counter() - t0
@@ -577,7 +591,12 @@ class BaseValidator(ABC, Generic[T]):
         if Store.CUDA:
             torch.cuda.set_device(get_local_rank() % torch.cuda.device_count())
         if distributed:
-            torch.distributed.init_process_group(backend='nccl' if Store.CUDA else 'gloo')
+            # RCCL needs one GPU per rank; with more ranks than GPUs (several processes per GPU: the host side
+            # of the sweep — file reads, Huffman decode, .pth writing — scales with processes)
+            # the one counters gather goes over gloo
+            backend = os.environ.get('OAKE_DIST_BACKEND') or (
+                'nccl' if Store.CUDA and get_world_size() <= torch.cuda.device_count() else 'gloo')
+            torch.distributed.init_process_group(backend=backend)
 
         # the unpinned behaviours of the un-vendored fork (oadp_amd/clip/settings.py), before the model exists
         from ..clip import settings as fork_settings

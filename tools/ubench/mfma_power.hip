@@ -39,6 +39,39 @@ __global__ __launch_bounds__(512) void mfma_kernel(const f16x8* __restrict__ fra
   if (s == 12345.678f) sink[0] = s;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// the same FLOPs per iteration from v_mfma_f32_32x32x16_f16: 10 instructions on a 160 x 64 strip... here a
+// (5 x 32) x (2 x 32) block of accumulator tiles = 160 accumulator registers, 5 + 2 operand fragments
+__global__ __launch_bounds__(512) void mfma32_kernel(const f16x8* __restrict__ frags, float* sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  f16x8 af[5], bf[2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) af[i] = frags[i * 64 + lane];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bf[j] = frags[(5 + j) * 64 + lane];
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  if (s == 12345.678f) sink[0] = s;
+}
+
 int main(int argc, char** argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
   hipDeviceProp_t prop;
@@ -50,7 +83,9 @@ int main(int argc, char** argv) {
   hipMalloc(&d_sink, 4);
   const char* names[3] = {"zeros", "ones", "random N(0,0.25)"};
   for (int rnd = 0; rnd < 2; ++rnd)
+  for (int shape = 0; shape < 2; ++shape)
   for (int mode = 0; mode < 3; ++mode) {
+    if (shape == 1 && mode == 1) continue;
     std::vector<_Float16> h(9 * 64 * 8);
     srand(7);
     for (auto& v : h) {
@@ -66,7 +101,11 @@ int main(int argc, char** argv) {
     const double flop_per_launch = (double)cus * 8 * 20 * 16384.0 * iters;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    mfma_kernel<<<cus, 512>>>(d_frags, d_sink, iters);  // warm
+    auto launch = [&]() {
+      if (shape == 0) mfma_kernel<<<cus, 512>>>(d_frags, d_sink, iters);
+      else mfma32_kernel<<<cus, 512>>>(d_frags, d_sink, iters);
+    };
+    launch();  // warm
     hipDeviceSynchronize();
     // launches back to back until `seconds` have passed; report the rate of the LAST half
     int n = 0;
@@ -74,7 +113,7 @@ int main(int argc, char** argv) {
     int last_n = 0;
     while (total_ms < seconds * 1e3) {
       hipEventRecord(e0);
-      for (int k = 0; k < 10; ++k) mfma_kernel<<<cus, 512>>>(d_frags, d_sink, iters);
+      for (int k = 0; k < 10; ++k) launch();
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms;
@@ -82,7 +121,7 @@ int main(int argc, char** argv) {
       total_ms += ms; n += 10;
       if (total_ms > seconds * 500) { last_ms += ms; last_n += 10; }
     }
-    printf("%-18s %7.0f TFLOP/s over the last %.2f s (%d launches of %.2f ms)\n", names[mode],
+    printf("%s %-18s %7.0f TFLOP/s over the last %.2f s (%d launches of %.2f ms)\n", shape ? "32x32x16" : "16x16x32", names[mode],
            flop_per_launch * last_n / (last_ms * 1e-3) / 1e12, last_ms * 1e-3, last_n, last_ms / last_n);
     fflush(stdout);
   }
