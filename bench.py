@@ -414,6 +414,11 @@ def main() -> int:
     args.max_batch = args.max_batch or DEFAULT_MAX_BATCH[args.mode] or args.batch
     args.image_wh = tuple(int(v) for v in args.image_size.lower().split('x'))
     args.lanes = max(1, int(os.environ.get('OAKE_BENCH_LANES', 2)))
+    # torch's intra-op pool for the host half of a step (blocks / objects: bbox math, expand, masks — tiny ops
+    # that each wake one OpenMP thread per core by default; the validators cap it the same way).
+    # The CPU baseline below runs with the full pool.
+    all_threads = torch.get_num_threads()
+    torch.set_num_threads(min(all_threads, int(os.environ.get('OAKE_BENCH_HOST_THREADS', 8))))
 
     sd = None
     model = None
@@ -589,7 +594,8 @@ def main() -> int:
             'roofline': roofline,
             'kernels': kernels,
             # (rank 0 at N=1 only: with more ranks the other processes would sit in teardown for its 10+ s)
-            'cpu_baseline': (None if (args.no_cpu_baseline or world > 1 or DRY_PLUMBING) else work.cpu_baseline()),
+            'cpu_baseline': (None if (args.no_cpu_baseline or world > 1 or DRY_PLUMBING)
+                             else (torch.set_num_threads(all_threads), work.cpu_baseline())[1]),
             'cpu_baseline_note': 'reported on rank 0 at N=1 only' if world > 1 else None,
         }
         print(json.dumps(line), flush=True)
