@@ -873,6 +873,10 @@ int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, 
   int max_out = 1;
   long max_ch_rw = 1, max_rh_rw = 1;
   for (auto& j : jobs) {
+    if (!j.tr && (long)j.ch > 100L * j.cw && j.rh < j.ch) {  // Pillow resamples these vertically first
+      std::swap(j.cw, j.ch); std::swap(j.rw, j.rh); std::swap(j.sx0, j.sy0); std::swap(j.cx, j.cy);
+      j.tr = 1;
+    }
     j.kh = ksize_for(j.cw, j.rw);
     j.kv = ksize_for(j.ch, j.rh);
     j.coefh_off = coef; coef += (long)j.rw * j.kh;

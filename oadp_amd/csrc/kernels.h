@@ -159,6 +159,12 @@ struct ResampleJob {
   long temp_off;       // byte offset of this job's horizontal-pass image
   long out_row;        // DT_F32 / DT_F16 output: the job's row of `out` [rows,3,out,out]
   uint8_t* u8_out;     // DT_U8 output: this job's rh x rw HWC destination (device)
+  // Pass order.  Pillow runs the horizontal pass first — except that a source more than 100 times taller
+  // than wide whose vertical pass reduces is resampled vertically first (Pillow 12.2, pinned empirically:
+  // tests/test_resample.py).  Such a job is stored TRANSPOSED (tr = 1: cw/ch, rw/rh, sx0/sy0, cx/cy swapped,
+  // run_resample does it): the kernels read the source and write the output through the transposition, so
+  // "horizontal, then vertical" in job space is vertical, then horizontal in the image.
+  int tr;
 };
 // out_dtype DT_F32 / DT_F16: normalised crops, job j -> out[j.out_row];
 // DT_U8: every job writes its own uint8 HWC image (rh x rw) to job.u8_out (`out` unused).

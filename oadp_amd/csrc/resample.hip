@@ -99,12 +99,15 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const ResampleJob* __re
   if (idx >= (long)jb.ch * jb.rw) return;
   const int y = idx / jb.rw, x = idx - (long)y * jb.rw;
   const int sy = jb.sy0 + y;
-  const bool row_ok = sy >= 0 && sy < height;
+  // job space (sy, sx) -> image (row, column); a transposed job walks image columns
+  const int sy_lim = jb.tr ? width : height, sx_lim = jb.tr ? height : width;
+  const long sy_step = jb.tr ? 3 : (long)width * 3, sx_step = jb.tr ? (long)width * 3 : 3;
+  const bool row_ok = sy >= 0 && sy < sy_lim;
   uint8_t* o = temp + jb.temp_off + idx * 3;
   if (jb.cw == jb.rw) {
     const int sx = jb.sx0 + x;
-    const bool ok = row_ok && sx >= 0 && sx < width;
-    const uint8_t* p = img + ((long)sy * width + sx) * 3;
+    const bool ok = row_ok && sx >= 0 && sx < sx_lim;
+    const uint8_t* p = img + sy * sy_step + sx * sx_step;
     o[0] = ok ? p[0] : 0;
     o[1] = ok ? p[1] : 0;
     o[2] = ok ? p[2] : 0;
@@ -114,11 +117,11 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const ResampleJob* __re
   const int xmin = bounds[jb.boundh_off + 2L * x], cnt = bounds[jb.boundh_off + 2L * x + 1];
   int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
   if (row_ok) {
-    const uint8_t* rowp = img + (long)sy * width * 3;
+    const uint8_t* rowp = img + sy * sy_step;
     for (int t = 0; t < cnt; ++t) {
       const int sx = jb.sx0 + xmin + t;
-      if (sx >= 0 && sx < width) {
-        const uint8_t* p = rowp + (long)sx * 3;
+      if (sx >= 0 && sx < sx_lim) {
+        const uint8_t* p = rowp + sx * sx_step;
         const int kv = k[t];
         s0 += p[0] * kv;
         s1 += p[1] * kv;
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ResampleJob* __re
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= out_size * out_size) return;
   const int oy = p / out_size, ox = p - oy * out_size;
-  const int ry = oy + jb.cy, rx = ox + jb.cx;  // position in the resized image
+  // position in the resized image, in job space (a transposed job: output (oy, ox) is its (ox, oy))
+  const int ry = (jb.tr ? ox : oy) + jb.cy, rx = (jb.tr ? oy : ox) + jb.cx;
   float r = 0.f, g = 0.f, b = 0.f;
   if (ry >= 0 && ry < jb.rh && rx >= 0 && rx < jb.rw) {
     const uint8_t* tcol = temp + jb.temp_off + (long)rx * 3;
@@ -181,7 +185,10 @@ __global__ __launch_bounds__(256) void resample_v_u8_kernel(const ResampleJob* _
   const ResampleJob jb = jobs[blockIdx.y];
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (long)jb.rh * jb.rw) return;
-  const int ry = p / jb.rw, rx = p - (long)ry * jb.rw;
+  // p walks the OUTPUT image row-major: rh x rw, or rw x rh (rows x columns) for a transposed job
+  const int ow = jb.tr ? jb.rh : jb.rw;
+  const int orow = p / ow, ocol = p - (long)orow * ow;
+  const int ry = jb.tr ? ocol : orow, rx = jb.tr ? orow : ocol;
   const uint8_t* tcol = temp + jb.temp_off + (long)rx * 3;
   uint8_t* o = jb.u8_out + p * 3;
   if (jb.ch == jb.rh) {

@@ -218,9 +218,10 @@ class Validator(BaseValidator[Batch]):
         # one device -> host copy per flush, left in flight while the next flush is prepared (base._flush)
         host = self._to_host(torch.cat(embs)) if embs else None
         meta = [(b.bboxes.shape[0], b.bboxes.half(), b.objectness.half()) for b in batches]
+        embed_dim = getattr(self._model.visual, 'output_dim', 512)  # (a flush without a single crop)
 
         def finish() -> list[dict]:
-            emb = host.get() if host is not None else torch.zeros(0, 512, dtype=torch.float16)
+            emb = host.get() if host is not None else torch.zeros(0, embed_dim, dtype=torch.float16)
             out, i = [], 0
             for n, bboxes, objectness in meta:
                 out.append(dict(embeddings=emb[i:i + n].clone(), bboxes=bboxes, objectness=objectness))

@@ -61,8 +61,17 @@ def _pass(img: np.ndarray, out_size: int, axis: int) -> np.ndarray:
     return np.moveaxis(out, 0, axis)
 
 
+def vertical_first(in_w: int, in_h: int, out_h: int) -> bool:
+    """Pillow's pass order.  Horizontal first — except for a source more than 100 times taller than wide whose
+    vertical pass reduces (Pillow 12.2; not in the documentation: pinned empirically against PIL.Image.resize
+    over the threshold and 377 random narrow shapes, tests/test_resample.py)."""
+    return in_h > 100 * in_w and out_h < in_h
+
+
 def resize_ref(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
-    """PIL.Image.fromarray(img).resize((out_w, out_h), BICUBIC) — horizontal pass, then vertical."""
+    """PIL.Image.fromarray(img).resize((out_w, out_h), BICUBIC): two passes with a uint8 intermediate."""
+    if vertical_first(img.shape[1], img.shape[0], out_h):
+        return _pass(_pass(img, out_h, 0), out_w, 1)
     return _pass(_pass(img, out_w, 1), out_h, 0)
 
 

@@ -38,3 +38,27 @@ def test_crop_matches_pillow():
     pil = PIL.Image.fromarray(img)
     for box in [(0.5, 1.5, 40.5, 60.5), (-10.2, -5.7, 50.1, 44.4), (100, 70, 140, 110), (2.5, 3.5, 4.5, 6.5)]:
         assert np.array_equal(resample_ref.crop_ref(img, box), np.asarray(pil.crop(box)))
+
+
+def test_pass_order_of_very_narrow_sources():
+    """Pillow resamples horizontally first — except a source more than 100 times taller than wide whose
+    vertical pass reduces, which goes vertically first (the uint8 intermediate makes the order visible).  The
+    rule is not documented; this pins `resample_ref.vertical_first` on both sides of every edge of it."""
+    cases = [(2, 2000, 224, 224), (19, 2000, 224, 224), (20, 2000, 224, 224), (2, 201, 224, 100), (2, 200, 224, 100),
+             (5, 501, 3, 100), (5, 500, 3, 100), (2, 300, 224, 299), (2, 300, 224, 301), (2, 300, 224, 600),
+             (29, 3000, 448, 448), (30, 3000, 448, 448), (2000, 2, 224, 224), (300, 2, 100, 224), (1, 500, 7, 50)]
+    seen = set()
+    for w, h, ow, oh in cases:
+        img = np.random.default_rng(w * 7 + h).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        ref = np.asarray(PIL.Image.fromarray(img).resize((ow, oh), PIL.Image.BICUBIC))
+        assert np.array_equal(resample_ref.resize_ref(img, ow, oh), ref), (w, h, ow, oh)
+        seen.add(resample_ref.vertical_first(w, h, oh))
+    assert seen == {True, False}
+    rng = np.random.default_rng(3)
+    for _ in range(60):  # random narrow shapes around the threshold
+        w = int(rng.choice([2, 3, 4, 5, 7, 9, 12]))
+        h = int(rng.integers(50, 1500))
+        ow, oh = int(rng.choice([2, 3, 5, 8, 50, 224])), int(rng.integers(2, 1800))
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        ref = np.asarray(PIL.Image.fromarray(img).resize((ow, oh), PIL.Image.BICUBIC))
+        assert np.array_equal(resample_ref.resize_ref(img, ow, oh), ref), (w, h, ow, oh)
