@@ -287,3 +287,44 @@ def test_lanes_are_independent_handles_on_their_own_streams(cuda):
         assert torch.equal(g, w)
     model.visual.close()
     assert not model.visual._lanes
+
+
+def _clip_like_statistics(sd, width=768, seed=5):
+    """Push the benign synthetic weights towards what a trained CLIP ViT looks like numerically: LayerNorm
+    gains spread over more than a decade with a few large ones, sizeable LayerNorm shifts, 'massive
+    activation' channels in the residual stream (a few channels of the class / positional embedding and of the
+    residual-branch biases tens of times larger than the rest), sharper attention logits."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {k: v.clone() for k, v in sd.items()}
+    big = torch.randperm(width, generator=g)[:4]
+    for k in sd:
+        if k.endswith(('ln_1.weight', 'ln_2.weight', 'ln_pre.weight', 'ln_post.weight')):
+            gain = torch.exp(torch.empty(width).uniform_(-1.6, 1.4, generator=g))  # 0.2 .. 4
+            gain[torch.randperm(width, generator=g)[:3]] *= 8.0
+            sd[k] = gain
+        elif k.endswith(('ln_1.bias', 'ln_2.bias', 'ln_pre.bias', 'ln_post.bias')):
+            sd[k] = torch.randn(width, generator=g) * 0.5
+        elif k.endswith(('out_proj.bias', 'c_proj.bias')):
+            sd[k][big] += torch.tensor([6.0, -5.0, 4.0, -7.0])  # outlier channels that grow layer by layer
+        elif k.endswith('in_proj_weight'):
+            sd[k][:2 * width] *= 1.8  # q and k: sharper softmax
+    sd['visual.class_embedding'][big] *= 40.0
+    sd['visual.positional_embedding'][:, big] *= 25.0
+    return sd
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
+def test_encode_image_clip_like_weight_statistics(cuda, dtype, tol):
+    """The 16-bit residual stream, the LayerNorm folded into the consuming GEMMs (gamma in W, row statistics
+    applied in the epilogue) and the GEMM-to-GEMM hand-off of (sum x, sum x^2) under hostile statistics:
+    residual rows whose mean and variance are dominated by a few channels, LayerNorm gains from 0.2 to 30.
+    Against the fp32 oracle, at the north-star tolerance."""
+    sd = _clip_like_statistics(synthetic_state_dict())
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48)
+    x = synthetic_images(48, seed=321)
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
+    out = model.encode_image(x.to(cuda), normalize=True, out_dtype=torch.float32)
+    assert torch.isfinite(out).all()
+    _check(out, ref, tol, tol)
+    small = model.encode_image(x[:5].to(cuda), normalize=True, out_dtype=torch.float32)  # non-persistent kernels
+    _check(small, ref[:5], tol, tol)
