@@ -320,7 +320,9 @@ OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int ite
  * 2 = 32 queries per wave (else 64), 4 = sequences longer than 64 keys share K / V through LDS between
  * the four waves of a block, 8 = objects mode: the object token's attention rides on an idle wave
  * of that kernel, 16 = sequences of at most 64 keys without a causal mask: the two waves of a (crop,
- * head) share its K / V in LDS, staged with LDS-DMA.  Default 31. */
+ * head) share its K / V in LDS, staged with LDS-DMA, 32 = sequences longer than 128 keys: one block of
+ * eight waves per (crop, head) reads K / V once (else two blocks of four read them twice; measured slower,
+ * so not in the default).  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
 /* GEMM configuration: -1 = automatic per shape, 0..10 = forced (see csrc/gemm.hip).
  * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel

@@ -512,14 +512,21 @@ struct ObjArgs {
   int mask_f16;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_coop_kernel(const T* __restrict__ qkv,
+// NW = 8 (L > 128; attention_variant bit 32, OFF by default): ONE block of eight waves per (crop, head)
+// instead of two blocks of four — K and V are read once per head instead of twice (objects mode, L = 197:
+// 1.41x -> 1.0x the algorithmic bytes).  Measured SLOWER, 16.3 vs 12.4 ms per objects step: at 136 registers
+// one eight-wave block fits a CU (8 waves, all meeting at every chunk barrier) where three four-wave blocks
+// do (12 waves, independent); at 128 registers it spills.  The kernel is latency-, not HBM-bound.
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_coop_kernel(const T* __restrict__ qkv,
                                                              T* __restrict__ out, int L, int H, int QG,
                                                              int causal, ObjArgs obj) {
   typedef typename T16<T>::vec8 vec8;
   constexpr int MT = 2;
+  static_assert(NW == 4 || NW == 8, "four or eight waves of 32 queries");
   __shared__ __attribute__((aligned(16))) T ks[64 * kVStride];
   __shared__ __attribute__((aligned(16))) T vs[64 * kVStride];
+  __shared__ __attribute__((aligned(16))) T ostage[NW > 4 ? 128 * kVStride : 8];  // output staging of waves 4..7
   __shared__ float mbias[256];  // objects mode: -100 * mask of the crop's patch keys, indexed by key
 
   const int tid = threadIdx.x;
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const T* base = qkv + (size_t)img * L * ld + h * kHeadDim;
   const int fr = lane & 15;
   const int g = lane >> 4;
-  const int q0 = qg * 128 + wid * 32;
+  const int q0 = qg * (32 * NW) + wid * 32;
   // the object token takes the first wave of the last block that has no queries of its own
   const bool is_obj = obj.qkv_y != nullptr && qg == QG - 1 && q0 >= L && q0 - 32 < L;
   const bool active = q0 < L || is_obj;  // (inactive waves still load and synchronise)
@@ -579,6 +586,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 
   // cooperative chunk load: thread -> rows (tid>>3) and (tid>>3)+32, 16-B chunk tid&7, of K and of V
+  // (eight waves: one row per thread)
   const int lr = tid >> 3, lc = tid & 7;
   // (macros, not lambdas: register arrays captured by a lambda end up in scratch)
   uint4 kreg0, kreg1, vreg0, vreg1;
@@ -589,15 +597,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     _r1 = _r1 < L ? _r1 : L - 1;                                                             \
     kreg0 = *reinterpret_cast<const uint4*>(base + (size_t)_r0 * ld + C + lc * 8);           \
     vreg0 = *reinterpret_cast<const uint4*>(base + (size_t)_r0 * ld + 2 * C + lc * 8);       \
-    kreg1 = *reinterpret_cast<const uint4*>(base + (size_t)_r1 * ld + C + lc * 8);           \
-    vreg1 = *reinterpret_cast<const uint4*>(base + (size_t)_r1 * ld + 2 * C + lc * 8);       \
+    if (NW == 4) {                                                                           \
+      kreg1 = *reinterpret_cast<const uint4*>(base + (size_t)_r1 * ld + C + lc * 8);         \
+      vreg1 = *reinterpret_cast<const uint4*>(base + (size_t)_r1 * ld + 2 * C + lc * 8);     \
+    }                                                                                        \
   } while (0)
 #define OAKE_PUBLISH()                                                                       \
   do {                                                                                       \
     *reinterpret_cast<uint4*>(ks + lr * kVStride + lc * 8) = kreg0;                          \
     *reinterpret_cast<uint4*>(vs + lr * kVStride + lc * 8) = vreg0;                          \
-    *reinterpret_cast<uint4*>(ks + (lr + 32) * kVStride + lc * 8) = kreg1;                   \
-    *reinterpret_cast<uint4*>(vs + (lr + 32) * kVStride + lc * 8) = vreg1;                   \
+    if (NW == 4) {                                                                           \
+      *reinterpret_cast<uint4*>(ks + (lr + 32) * kVStride + lc * 8) = kreg1;                 \
+      *reinterpret_cast<uint4*>(vs + (lr + 32) * kVStride + lc * 8) = vreg1;                 \
+    }                                                                                        \
   } while (0)
 
   // Work that only pads is skipped in whole 16-row tiles (wave-uniform branches): a wave with n valid
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // O through LDS (the K / V chunk buffers are free after the loop's last barrier; wave w takes 32 rows
   // of ks or vs) so that it leaves as 8 rows x 128 B per store instead of 16 quarter lines
   T* obase = out + (size_t)img * L * C + h * kHeadDim;
-  T* stage = ((wid & 2) ? vs : ks) + (wid & 1) * 32 * kVStride;
+  T* stage = wid >= 4 ? ostage + (wid - 4) * 32 * kVStride : ((wid & 2) ? vs : ks) + (wid & 1) * 32 * kVStride;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (mt >= nmt) continue;
@@ -791,18 +803,19 @@ __global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* 
 
 }  // namespace
 
-// LaunchOpts::attention_variant bits (default 31 = all set):
+// LaunchOpts::attention_variant bits (default 31: all but the last):
 //   1  ds_read_b64_tr_b16 V fragments (else 16-bit LDS gathers)
 //   2  32 queries per wave (else 64: twice the registers, half the waves)
 //   4  sequences longer than one key chunk share K / V through LDS (attention_coop_kernel)
 //   8  objects mode: the object token's attention rides on an idle wave of that kernel
 //  16  L <= 64 without a causal mask: two waves share an item's K / V in LDS (attention_pair_kernel)
+//  32  L > 128: one block of eight waves per (crop, head) in attention_coop_kernel (else two of four) — slower, off
 namespace {
 struct AttnBits {
-  bool use_tr, q32, coop, fuse_obj, pair;
+  bool use_tr, q32, coop, fuse_obj, pair, coop8;
   explicit AttnBits(const LaunchOpts* o) {
     const int v = o ? o->attention_variant : 31;
-    use_tr = v & 1; q32 = v & 2; coop = v & 4; fuse_obj = v & 8; pair = v & 16;
+    use_tr = v & 1; q32 = v & 2; coop = v & 4; fuse_obj = v & 8; pair = v & 16; coop8 = v & 32;
   }
 };
 }  // namespace
@@ -841,8 +854,9 @@ static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, i
 bool attention_fuses_object_token(int L, const LaunchOpts* opts) {
   // needs the cooperative kernel and a wave without queries in the last block of each head
   const AttnBits b(opts);
-  const int tail = L - 128 * ((L + 127) / 128 - 1);
-  return b.coop && b.use_tr && b.fuse_obj && L > 64 && L <= 256 && tail <= 96;
+  const int per = b.coop8 && L > 128 ? 256 : 128;  // queries per block
+  const int tail = L - per * ((L + per - 1) / per - 1);
+  return b.coop && b.use_tr && b.fuse_obj && L > 64 && L <= 256 && tail <= per - 32;
 }
 
 hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int L, int heads,
@@ -855,17 +869,28 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
   if (bits.coop && bits.use_tr && L > 64) {
-    const int QG = (L + 127) / 128;
-    const dim3 grid(n * heads * QG), blk(256);
+    const bool eight = bits.coop8 && L > 128;
+    const int per = eight ? 256 : 128;
+    const int QG = (L + per - 1) / per;
+    const dim3 grid(n * heads * QG), blk(eight ? 512 : 256);
     const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
-    if (dtype16 == DT_F16)
-      OAKE_LAUNCH(attention_coop_kernel<f16_t>, grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
-                         reinterpret_cast<f16_t*>(out), L, heads, QG, causal, obj);
-    else if (dtype16 == DT_BF16)
-      OAKE_LAUNCH(attention_coop_kernel<bf16_t>, grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
-                         reinterpret_cast<bf16_t*>(out), L, heads, QG, causal, obj);
-    else
+    if (dtype16 == DT_F16) {
+      if (eight)
+        OAKE_LAUNCH((attention_coop_kernel<f16_t, 8>), grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
+                    reinterpret_cast<f16_t*>(out), L, heads, QG, causal, obj);
+      else
+        OAKE_LAUNCH((attention_coop_kernel<f16_t, 4>), grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
+                    reinterpret_cast<f16_t*>(out), L, heads, QG, causal, obj);
+    } else if (dtype16 == DT_BF16) {
+      if (eight)
+        OAKE_LAUNCH((attention_coop_kernel<bf16_t, 8>), grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
+                    reinterpret_cast<bf16_t*>(out), L, heads, QG, causal, obj);
+      else
+        OAKE_LAUNCH((attention_coop_kernel<bf16_t, 4>), grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
+                    reinterpret_cast<bf16_t*>(out), L, heads, QG, causal, obj);
+    } else {
       return hipErrorInvalidValue;
+    }
     return hipGetLastError();
   }
   if (bits.pair && bits.use_tr && L <= 64 && !causal && qkv_y == nullptr) {
