@@ -63,3 +63,27 @@ def test_modes_produce_a_contract_line(mode, extra):
     sus = rf['sustained']
     assert sus['live'] and 1000 < sus['random_operands'] <= sus['zero_operands'] * 1.02 < 2700
     assert 0 < line['mfma_sustained_frac_e2e'] < 1
+
+
+@pytest.mark.gpu
+def test_two_validator_ranks_share_one_gpu(tmp_path):
+    """More ranks than GPUs (the host side of the sweep scales with processes): two full
+    validators on the DistributedSampler halves of one image set, one GPU, gloo for the counters gather —
+    every image gets its file exactly once."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    root = tmp_path / 'set'
+    env = dict(os.environ, PYTHONPATH=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        str(ROOT / 'tools' / 'sweep_ranks.py'), '48', 'blocks', str(root)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if 'rank(s) on one GPU' in ln]
+    assert len(line) == 1 and ' 2 rank(s)' in line[0] and ': 48 images, 1296 crops' in line[0], r.stdout[-2000:]
+    files = sorted(p.name for p in (root / 'out_blocks_2').glob('*.pth'))
+    assert files == [f'{i:012d}.pth' for i in range(48)]
