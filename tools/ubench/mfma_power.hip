@@ -13,6 +13,10 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ORDER 0: consecutive MFMAs change the FIRST operand (the W fragment in gemm.hip) and keep the second for four
+// instructions (the production loop order); ORDER 1: they keep the first operand for five instructions and
+// change the second.  Same instructions, same data: does the operand that stays matter for power?
+template <int ORDER>
 __global__ __launch_bounds__(512) void mfma_kernel(const f16x8* __restrict__ frags, float* sink, int iters) {
   const int lane = threadIdx.x & 63;
   f16x8 af[5], bf[4];
@@ -26,10 +30,18 @@ __global__ __launch_bounds__(512) void mfma_kernel(const f16x8* __restrict__ fra
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < iters; ++it) {
+    if (ORDER == 0) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+      for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   float s = 0.f;
 #pragma unroll
@@ -83,9 +95,9 @@ int main(int argc, char** argv) {
   hipMalloc(&d_sink, 4);
   const char* names[3] = {"zeros", "ones", "random N(0,0.25)"};
   for (int rnd = 0; rnd < 2; ++rnd)
-  for (int shape = 0; shape < 2; ++shape)
+  for (int shape = 0; shape < 3; ++shape)
   for (int mode = 0; mode < 3; ++mode) {
-    if (shape == 1 && mode == 1) continue;
+    if (shape >= 1 && mode == 1) continue;
     std::vector<_Float16> h(9 * 64 * 8);
     srand(7);
     for (auto& v : h) {
@@ -102,7 +114,8 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
-      if (shape == 0) mfma_kernel<<<cus, 512>>>(d_frags, d_sink, iters);
+      if (shape == 0) mfma_kernel<0><<<cus, 512>>>(d_frags, d_sink, iters);
+      else if (shape == 2) mfma_kernel<1><<<cus, 512>>>(d_frags, d_sink, iters);
       else mfma32_kernel<<<cus, 512>>>(d_frags, d_sink, iters);
     };
     launch();  // warm
@@ -121,7 +134,7 @@ int main(int argc, char** argv) {
       total_ms += ms; n += 10;
       if (total_ms > seconds * 500) { last_ms += ms; last_n += 10; }
     }
-    printf("%s %-18s %7.0f TFLOP/s over the last %.2f s (%d launches of %.2f ms)\n", shape ? "32x32x16" : "16x16x32", names[mode],
+    printf("%s %-18s %7.0f TFLOP/s over the last %.2f s (%d launches of %.2f ms)\n", shape == 1 ? "32x32x16" : (shape == 2 ? "16x16x32 first operand kept" : "16x16x32"), names[mode],
            flop_per_launch * last_n / (last_ms * 1e-3) / 1e12, last_ms * 1e-3, last_n, last_ms / last_n);
     fflush(stdout);
   }
