@@ -324,7 +324,7 @@ OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int ite
  * eight waves per (crop, head) reads K / V once (else two blocks of four read them twice; measured slower,
  * so not in the default).  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
-/* GEMM configuration: -1 = automatic per shape, 0..10 = forced (see csrc/gemm.hip).
+/* GEMM configuration: -1 = automatic per shape, 0..11 = forced (see csrc/gemm.hip).
  * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel
  * entry points of the calling thread; a handle's own switches are set with oake_set_option. */
 OAKE_API int oake_debug_set_gemm_variant(int variant);
@@ -347,7 +347,7 @@ OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
  *                               rows ln_post reads): K / V projections of all tokens, everything else of
  *                               that block for one row per image.  0 = run the block for every token as
  *                               the reference does (A/B runs, tests).  Default 1.
- *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default), 0..10 forced (csrc/gemm.hip)
+ *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default), 0..11 forced (csrc/gemm.hip)
  *   OAKE_OPT_GEMM_PANEL         GEMM tile order, as oake_debug_set_gemm_panel.  Default 0.
  *   OAKE_OPT_ATTENTION_VARIANT  bit set, as oake_debug_set_attention_variant.  Default 31.
  *   OAKE_OPT_PATCH_DIRECT       conv1 gathers its patch rows straight from a 16-bit NCHW input batch (no
