@@ -322,7 +322,9 @@ OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int ite
  * of that kernel, 16 = sequences of at most 64 keys without a causal mask: the two waves of a (crop,
  * head) share its K / V in LDS, staged with LDS-DMA, 32 = sequences longer than 128 keys: one block of
  * eight waves per (crop, head) reads K / V once (else two blocks of four read them twice; measured slower,
- * so not in the default).  Default 31. */
+ * so not in the default), 64 = sequences of 65..208 keys: the whole K / V of a (crop, head) is brought into
+ * LDS up front with LDS-DMA and the key loop runs without barriers or global accesses (measured equal, so not
+ * in the default either).  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
 /* GEMM configuration: -1 = automatic per shape, 0..11 = forced (see csrc/gemm.hip).
  * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel

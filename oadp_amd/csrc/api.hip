@@ -1656,7 +1656,7 @@ int oake_debug_set_gemm_trace(void* d_trace) {
 }
 
 int oake_debug_set_attention_variant(int variant) {
-  t_debug_opts.attention_variant = variant & 63;
+  t_debug_opts.attention_variant = variant & 127;
   return OAKE_OK;
 }
 
@@ -1666,7 +1666,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
     case OAKE_OPT_CLS_LAST: h->cls_last = value ? 1 : 0; return OAKE_OK;
     case OAKE_OPT_GEMM_VARIANT: h->opts.gemm_variant = value < 0 ? -1 : value; return OAKE_OK;
     case OAKE_OPT_GEMM_PANEL: h->opts.gemm_panel = value; return OAKE_OK;
-    case OAKE_OPT_ATTENTION_VARIANT: h->opts.attention_variant = value & 63; return OAKE_OK;
+    case OAKE_OPT_ATTENTION_VARIANT: h->opts.attention_variant = value & 127; return OAKE_OK;
     case OAKE_OPT_PATCH_DIRECT: h->patch_direct = value ? 1 : 0; return OAKE_OK;
     default: return fail(h, OAKE_ERR_INVALID, "unknown option " + std::to_string(option));
   }

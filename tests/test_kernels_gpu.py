@@ -175,8 +175,8 @@ def _attention_ref(qkv, n, l, heads):
 
 
 # bit 2: K / V shared through LDS for l > 64; bit 4: persistent loader-wave kernel for l <= 64; bit 5 (63):
-# eight-wave blocks for l > 128 (197, 130, 300 below)
-@pytest.mark.parametrize('use_tr', [0, 1, 2, 3, 7, 31, 63])
+# eight-wave blocks for l > 128 (197, 130, 300 below); bit 6 (95): whole K / V in LDS for 64 < l <= 208
+@pytest.mark.parametrize('use_tr', [0, 1, 2, 3, 7, 31, 63, 95])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('n,l,heads', [(1, 50, 2), (3, 50, 12), (2, 197, 2), (5, 64, 3), (2, 17, 1),
                                        (1, 130, 1), (3, 77, 8), (2, 65, 1), (1, 300, 2), (1, 1, 1),
