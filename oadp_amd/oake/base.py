@@ -111,8 +111,12 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
     def __len__(self) -> int:
         return len(self.ids)
 
+    def _image_path(self, id_: int) -> str:
+        # torchvision CocoDetection._load_image: <root>/<file_name>
+        return os.path.join(self.root, self.coco.loadImgs([id_])[0]['file_name'])
+
     def _load_image(self, id_: int) -> PIL.Image.Image | EncodedImage:
-        path = os.path.join(self.root, self.coco.loadImgs([id_])[0]['file_name'])
+        path = self._image_path(id_)
         if self._device_decode:
             data = pathlib.Path(path).read_bytes()
             size = jpeg_size(data)

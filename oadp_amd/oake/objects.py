@@ -152,11 +152,12 @@ class COCODataset(BaseDataset[Batch]):
 
 
 class LVISDataset(COCODataset):
+    """LVIS annotations name their images by ``coco_url`` (train2017/... or val2017/... under the COCO root),
+    reference objects.py:190-196; decoding — host PIL or device — is the base class's."""
 
-    def _load_image(self, id_: int) -> PIL.Image.Image:
+    def _image_path(self, id_: int) -> str:
         info = self.coco.loadImgs([id_])[0]
-        path = info['coco_url'].replace('http://images.cocodataset.org/', '')
-        return PIL.Image.open(os.path.join(self.root, path)).convert('RGB')
+        return os.path.join(self.root, info['coco_url'].replace('http://images.cocodataset.org/', ''))
 
 
 DATASETS = dict(COCODataset=COCODataset, LVISDataset=LVISDataset)

@@ -339,3 +339,21 @@ def test_pinned_pool_reuses_byte_buffers(monkeypatch):
     pool.release(s4)
     s5, f = pool.acquire(1 << 22, torch.uint8)  # nothing free fits: the free buffer is replaced by a larger one
     assert s5 == s0 and allocs[-1] == 1 << 22 and f.numel() == 1 << 22
+
+
+def test_lvis_dataset_resolves_images_by_coco_url(coco, tmp_path, monkeypatch):
+    """LVISDataset (reference objects.py:190-196): the image file comes from ``coco_url`` under the COCO root,
+    not from ``file_name``; everything else is COCODataset — the same batch, on the PIL path and (bytes handed
+    over untouched) on the device-decode path."""
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    from oadp_amd.clip.preprocess import Preprocess
+    pre = Preprocess(224)
+    root_images = pathlib.Path(coco['root'])          # .../images
+    common = dict(annFile=coco['annFile'], transform=pre, grid=14, proposal_file=coco['proposal_file'],
+                  proposal_sorted=True)
+    a = objects.COCODataset(str(root_images), output_dir=str(tmp_path / 'a'), **common)
+    b = objects.LVISDataset(str(root_images.parent), output_dir=str(tmp_path / 'b'), **common)
+    assert b._image_path(b.ids[0]).endswith(f'images/{b.ids[0]:012d}.png')
+    for i in range(len(a)):
+        x, y = a[i], b[i]
+        assert torch.equal(x.objects, y.objects) and torch.equal(x.bboxes, y.bboxes) and torch.equal(x.masks, y.masks)
