@@ -109,3 +109,30 @@ def test_blocks_batch_matches_per_image_path(cuda):
             assert torch.equal(out[i:i + k], ref), (w, h, dt)
             i += k
         assert i == out.shape[0]
+
+
+@pytest.mark.parametrize('squash', [False, True])
+def test_crop_boxes_of_every_kind_match_pillow(cuda, squash):
+    """preprocess(image.crop(box)) on the device vs PIL for boxes inside the image, across every border, tiny,
+    taller than wide and random, on sources from 37x53 to 2600x1900 — one batched call, bit for bit."""
+    model, _ = clip.load(synthetic_state_dict(**_synth.TINY), max_batch=4)
+    rng = np.random.default_rng(9)
+    arrs = [_img(640, 480, 1), _img(333, 517, 2), _img(37, 53, 3), _img(1700, 1134, 4), _img(2600, 1900, 5)]
+    boxes = []
+    for a in arrs:
+        h, w = a.shape[:2]
+        bs = [(0, 0, w, h), (-20.5, -10.5, w * 0.6, h * 0.7), (w * 0.3, h * 0.2, w + 33.2, h + 5.5),
+              (w * 0.45, h * 0.45, w * 0.45 + 4.2, h * 0.45 + 9.7), (w * 0.1, h * 0.05, w * 0.2, h * 0.95)]
+        for _ in range(6):
+            x1, y1 = rng.uniform(-30, w * 0.8), rng.uniform(-30, h * 0.8)
+            bs.append((x1, y1, x1 + rng.uniform(4, w), y1 + rng.uniform(4, h)))
+        boxes.append([tuple(float(v) for v in b) for b in bs])
+    out = model.visual.crop_resize_normalize_batch([torch.from_numpy(a).to(cuda) for a in arrs], boxes,
+                                                   squash=squash, out_dtype=torch.float32)
+    host = Preprocess(224, squash=squash)
+    i = 0
+    for a, bs in zip(arrs, boxes):
+        pil = PIL.Image.fromarray(a)
+        for b in bs:
+            assert torch.equal(out[i].cpu(), host(pil.crop(b))), (a.shape, b, squash)
+            i += 1
