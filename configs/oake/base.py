@@ -17,11 +17,12 @@ val = dict(
 # crops per encoder pass (build-side batching; the reference encodes one image at a time)
 batch_size = 256
 
-# MI355X fast path (not in the reference): decode + preprocess on the device, no DataLoader workers —
-#   --override .train.dataloader.dataset.device_decode:True .train.dataloader.num_workers:0
-#              .val.dataloader.dataset.device_decode:True   .val.dataloader.num_workers:0
-# (files are read by the main process, Huffman passes run on `decode_threads` native threads;
-# measured 2.8 k images/s for globals and 30 k crops/s for blocks on one GPU, tools/sweep_bench.py)
+# MI355X fast path (not in the reference): decode + preprocess on the device —
+#   --override .train.dataloader.dataset.device_decode:True .val.dataloader.dataset.device_decode:True
+# (the validator then runs without DataLoader workers: files are read by a prefetch thread of the process,
+# Huffman passes run on `decode_threads` native threads; measured per GPU, files -> .pth: 5-6 k images/s for
+# globals (12 k with two processes per GPU), 85-94 k crops/s for blocks, 23.6 k crops/s for objects —
+# DESIGN.md §5.5, profiles/r02_sweep_1gpu.log)
 decode_threads = 32
 
 # Behaviours of the un-vendored LutingWang/CLIP fork / todd that the reference's sources do not pin

@@ -378,6 +378,14 @@ class BaseValidator(ABC, Generic[T]):
         config = Config(config)
         if Store.DRY_RUN:
             config['num_workers'] = 0
+        if config.get('num_workers', 0) > 0 and getattr(config.get('dataset'), '_device_decode', False):
+            # device decode hands over file bytes: through DataLoader workers every sample crosses a process
+            # boundary first (measured 117 vs 3 135 images/s in blocks mode, profiles/r02_sweep_1gpu.log); the
+            # prefetch thread of `_items` reads the files instead
+            if get_rank() == 0:
+                print(f'[{self.name}] device_decode: num_workers {config["num_workers"]} -> 0 '
+                      f'(files are read by a prefetch thread of this process)', flush=True)
+            config['num_workers'] = 0
         world = get_world_size()
         if world > 1:
             config['sampler'] = torch.utils.data.distributed.DistributedSampler(

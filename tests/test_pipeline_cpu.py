@@ -357,3 +357,16 @@ def test_lvis_dataset_resolves_images_by_coco_url(coco, tmp_path, monkeypatch):
     for i in range(len(a)):
         x, y = a[i], b[i]
         assert torch.equal(x.objects, y.objects) and torch.equal(x.bboxes, y.bboxes) and torch.equal(x.masks, y.masks)
+
+
+def test_device_decode_switches_dataloader_workers_off(coco, tmp_path, capsys):
+    """device_decode hands over file bytes; through DataLoader workers every sample would cross a process
+    boundary first (27x slower, profiles/r02_sweep_1gpu.log): the validator reads the files itself instead."""
+    dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 'o'),
+                             transform=_synth.preprocess(), device_decode=True), num_workers=3)
+    v = globals_.Validator('g', _synth.OracleModel(), dataloader=dl, device='cpu')
+    assert v._dataloader.num_workers == 0
+    assert 'num_workers 3 -> 0' in capsys.readouterr().out
+    dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 'p'),
+                             transform=_synth.preprocess()), num_workers=1)
+    assert globals_.Validator('g', _synth.OracleModel(), dataloader=dl, device='cpu')._dataloader.num_workers == 1

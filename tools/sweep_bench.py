@@ -39,8 +39,9 @@ sd = synthetic_state_dict()
 for cls, tag, bs in ((globals_.Validator, 'globals', 256), (blocks.Validator, 'blocks', 1024)):
     if tag not in only:
         continue
+    # (device decode through DataLoader workers is no longer a configuration: the validator switches the workers
+    # off — it measured 117 vs 3 135 images/s in blocks mode, profiles/r02_sweep_1gpu.log)
     for mode, kw, nw in (('host PIL decode + PIL preprocess', {}, workers),
-                         ('device decode + preprocess, DataLoader workers', dict(device_decode=True), workers),
                          ('device decode + preprocess, no workers', dict(device_decode=True), 0)):
         out = root / f'{tag}_{len(kw)}_{nw}'
         model, pre = clip.load(sd, max_batch=512)
