@@ -687,6 +687,10 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(FrameDev f, const int16_
 __device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ p, int stride, int dw, int dh,
                                          int fh, int fv, int x, int y) {
   if (fh == 1 && fv == 1) return p[(long)y * stride + x];
+  // jdsample.c jinit_upsampler: the fancy (triangle) filters are only installed for components more than two
+  // samples wide; narrower ones (images up to 4 pixels wide) are upsampled by plain replication
+  // (h2v1_upsample / h2v2_upsample).  Found by tools/jpeg_fuzz.py.
+  if (fh == 2 && dw <= 2) return p[(long)(fv == 2 ? y >> 1 : y) * stride + (x >> 1)];
   if (fh == 2 && fv == 1) {  // h2v1_fancy_upsample
     const uint8_t* row = p + (long)y * stride;
     const int i = x >> 1;

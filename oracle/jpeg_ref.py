@@ -449,6 +449,10 @@ def decode(data: bytes, progressive_ok: bool = False) -> np.ndarray:
         fh, fv = hmax // c.h, vmax // c.v
         if (fh, fv) == (1, 1):
             pass
+        elif fh == 2 and fv in (1, 2) and dw <= 2:
+            # jdsample.c jinit_upsampler: the fancy filters need downsampled_width > 2; narrower components
+            # (images up to 4 pixels wide) get h2v1_upsample / h2v2_upsample = plain replication
+            plane = np.repeat(np.repeat(plane, fv, axis=0), 2, axis=1)
         elif (fh, fv) == (2, 1):
             plane = upsample_h2v1(plane)
         elif (fh, fv) == (2, 2):

@@ -31,7 +31,9 @@ def _pil(data):
 
 
 CASES = [(h, w, ss, q, kind)
-         for (h, w) in [(8, 8), (1, 1), (7, 9), (17, 33), (37, 53), (64, 48), (33, 16)]
+         # (widths <= 4: libjpeg installs its fancy chroma upsampling only above two chroma samples per row)
+         for (h, w) in [(8, 8), (1, 1), (7, 9), (17, 33), (37, 53), (64, 48), (33, 16), (15, 1), (14, 3), (53, 4),
+                        (52, 2), (6, 5)]
          for ss in (0, 1, 2) for q in (30, 90) for kind in ('noise', 'grad')]
 
 
@@ -138,7 +140,8 @@ def test_host_huffman_restart_optimized_info():
 
 GPU_CASES = [(480, 640, 2, 85, 'grad'), (427, 640, 2, 75, 'noise'), (333, 500, 1, 90, 'grad'),
              (224, 224, 0, 95, 'noise'), (1, 1, 2, 50, 'grad'), (17, 33, 2, 60, 'noise'), (9, 7, 1, 60, 'noise'),
-             (1134, 1700, 2, 80, 'grad')]
+             (1134, 1700, 2, 80, 'grad'), (480, 1, 2, 28, 'noise'), (153, 4, 2, 34, 'grad'), (7, 4, 1, 93, 'noise'),
+             (14, 3, 2, 76, 'grad'), (345, 2, 1, 91, 'noise'), (9, 5, 2, 70, 'noise')]
 
 
 @pytest.mark.gpu
