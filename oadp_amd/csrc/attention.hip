@@ -643,7 +643,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     // the 24 wave-chunks of a head) — as straight-line code: no per-score validity tests, no guards around
     // the tiles, S accumulators started from the MFMA's zero operand.  The general path below measured ~25
     // VALU instructions per score, 3x the matrix work; this one ~5.  Same operations in the same order.
-    const bool fast = active && !is_obj && !causal && nmt == 2 && nkt == 4;
+    const bool fast = active && !is_obj && !causal && nmt == 2 && L - k0 >= 64;  // (nkt == 4 also holds for 49..63 keys)
     if (fast) {
       const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 sacc[4][MT];
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (causal && !is_obj && k0 > q0 + 31) break;  // every later chunk is masked out completely
     const int nkt = L - k0 >= 64 ? 4 : (L - k0 + 15) >> 4;
     const int nks = (nkt + 1) >> 1;
-    const bool fast = !is_obj && !causal && nmt == 2 && nkt == 4;
+    const bool fast = !is_obj && !causal && nmt == 2 && L - k0 >= 64;  // (nkt == 4 also holds for 49..63 keys)
     f32x4 sacc[4][MT];
     if (fast) {
       const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -180,7 +180,9 @@ def _attention_ref(qkv, n, l, heads):
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('n,l,heads', [(1, 50, 2), (3, 50, 12), (2, 197, 2), (5, 64, 3), (2, 17, 1),
                                        (1, 130, 1), (3, 77, 8), (2, 65, 1), (1, 300, 2), (1, 1, 1),
-                                       (64, 50, 12), (7, 33, 5)])
+                                       (64, 50, 12), (7, 33, 5),
+                                       # a last chunk of 49..63 keys: four key tiles, the last one partly valid
+                                       (1, 114, 2), (4, 182, 10), (2, 253, 9), (1, 127, 5), (3, 113, 3)])
 def test_attention(lib, cuda, dtype, n, l, heads, use_tr):
     g = torch.Generator(device='cpu').manual_seed(n * 100 + l + heads)
     qkv = torch.randn(n * l, 3 * heads * 64, generator=g)

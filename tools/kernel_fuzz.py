@@ -1,0 +1,90 @@
+"""Randomised shapes through the GEMM epilogues and the attention kernels against fp32 torch (GPU box): M from 1
+to 30 000 (ragged tiles, one row, several tiles per persistent block), N a multiple of 8 up to 3 200, K a multiple of
+64 up to 3 072, f16 and bf16, the automatic kernel choice; bias / QuickGELU / LayerNorm-folded / residual epilogues
+incl. the per-slice row sums; attention with 1..6 items, 1..300 keys, 1..12 heads.  usage: kernel_fuzz.py [n=200] [seed=0]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oadp_amd import _lib
+lib = _lib.load()
+dev = torch.device('cuda:0')
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+DT = {torch.float16: _lib.OAKE_F16, torch.bfloat16: _lib.OAKE_BF16}
+s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+bad = 0
+def check(tag, got, ref, tol, info):
+    global bad
+    err = (got.float() - ref).abs()
+    lim = tol + tol * ref.abs()
+    if not torch.isfinite(got.float()).all() or bool((err > lim).any()):
+        bad += 1
+        print('MISMATCH', tag, info, 'max err', float(err.max()), 'nan' if not torch.isfinite(got.float()).all() else '')
+for it in range(n_cases):
+    dtype = torch.float16 if rng.random() < 0.6 else torch.bfloat16
+    r = rng.random()
+    m = int(rng.integers(1, 400)) if r < 0.4 else (int(rng.integers(400, 5000)) if r < 0.85 else int(rng.integers(5000, 30000)))
+    n = 8 * int(rng.integers(1, 401))
+    k = 64 * int(rng.integers(1, 49))
+    if m * n > 40_000_000:
+        n = max(8, (40_000_000 // m) // 8 * 8)
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(dev)
+    w32 = torch.randn(n, k, generator=g) * k ** -0.5
+    w = w32.to(dtype).to(dev)
+    bias = torch.randn(n, generator=g).to(dev)
+    info = (m, n, k, str(dtype).split('.')[-1])
+    tol = 3e-3 if dtype == torch.float16 else 2.5e-2
+    kind = int(rng.integers(0, 4))
+    if kind == 0:    # bias / QuickGELU epilogues
+        gelu = int(rng.integers(0, 2))
+        c = torch.full((m, n), float('nan'), dtype=dtype, device=dev)
+        rc = lib.oake_debug_gemm16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, DT[dtype], gelu, s)
+        if rc: bad += 1; print('RC', rc, 'gemm16', info); continue
+        ref = a.float() @ w.float().t() + bias
+        if gelu:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        check('gemm16' + ('+gelu' if gelu else ''), c, ref, tol, info)
+    elif kind == 1:  # LayerNorm folded in (row statistics travel as 16 slices of 64 columns: K <= 1024)
+        gelu = int(rng.integers(0, 2))
+        if k > 1024:
+            k = 64 * int(rng.integers(1, 17)); a = a[:, :k].contiguous(); w32 = w32[:, :k].contiguous(); info = (m, n, k, info[3])
+        x = (torch.randn(m, k, generator=g) * 1.5 + 0.3)
+        x[:, int(rng.integers(0, k))] *= 10.0
+        x = x.to(dtype).to(dev)
+        gamma = (1.0 + 0.3 * torch.randn(k, generator=g)).to(dev)
+        beta = (0.2 * torch.randn(k, generator=g)).to(dev)
+        w32d = w32.to(dev)
+        c = torch.full((m, n), float('nan'), dtype=dtype, device=dev)
+        rc = lib.oake_debug_ln_gemm16(x.data_ptr(), w32d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+                                      c.data_ptr(), m, n, k, DT[dtype], gelu, s)
+        if rc: bad += 1; print('RC', rc, 'ln_gemm16', info); continue
+        ref = torch.nn.functional.layer_norm(x.float(), (k,), gamma, beta, 1e-5) @ w32d.t() + bias
+        if gelu:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        check('ln_gemm16' + ('+gelu' if gelu else ''), c, ref, 1.5 * tol, info)
+    elif kind == 2:  # residual epilogue + row-sum slices
+        if n > 1024:
+            n = 8 * int(rng.integers(1, 129)); w = w[:n].contiguous(); bias = bias[:n].contiguous(); info = (m, n, k, info[3])
+        x0 = torch.randn(m, n, generator=g).to(dtype).to(dev)
+        x = x0.clone()
+        part = torch.full((m, 16, 2), float('nan'), device=dev)
+        rc = lib.oake_debug_gemm_resid16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), part.data_ptr(), m, n, k, DT[dtype], s)
+        if rc: bad += 1; print('RC', rc, 'resid16', info); continue
+        ref = x0.float() + a.float() @ w.float().t() + bias
+        check('resid16', x, ref, 1.5 * tol, info)
+    else:            # attention
+        nn_, L, heads = int(rng.integers(1, 7)), int(rng.integers(1, 301)), int(rng.integers(1, 13))
+        qkv = torch.randn(nn_ * L, 3 * heads * 64, generator=g)
+        qkv[:, :heads * 64] *= 0.35
+        qkv = qkv.to(dtype).to(dev)
+        out = torch.zeros(nn_ * L, heads * 64, dtype=dtype, device=dev)
+        rc = lib.oake_debug_attention(qkv.data_ptr(), out.data_ptr(), nn_, L, heads, DT[dtype], s)
+        if rc: bad += 1; print('RC', rc, 'attention', (nn_, L, heads)); continue
+        q, kk, v = qkv.float().view(nn_, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        ref = (torch.softmax(q @ kk.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(nn_ * L, heads * 64)
+        check('attention', out, ref, tol, (nn_, L, heads, info[3]))
+    torch.cuda.synchronize()
+print(f'kernel_fuzz seed {seed}: {n_cases} random cases, {bad} mismatches')
+sys.exit(1 if bad else 0)
