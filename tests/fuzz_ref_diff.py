@@ -5,9 +5,10 @@ tools/gen_golden.py, nothing of them is copied).  Far more cases than the commit
   _mask for thousands of random (foreground, object) pairs incl. fractional and degenerate ones;
   _expand + the crop boxes PIL derives from it for random proposal sets on random image sizes.
 Integer / index results must be identical; the float boxes of _expand to 1e-3 px (torch's vectorised sqrt differs
-by an ulp between code paths) with identical PIL crop boxes.  usage: ref_diff_fuzz.py [seed=0]"""
+by an ulp between code paths) with identical PIL crop boxes.  (Lives under tests/ because it also drives oracle/; not collected by pytest: run it by hand.)
+usage: python tests/fuzz_ref_diff.py [seed=0]"""
 import pathlib, sys, types
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1] / 'tools'))
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 import numpy as np, PIL.Image, torch
 import gen_golden as gg
@@ -95,6 +96,6 @@ for _ in range(300):
             # (a float box within an ulp of a .5 boundary may round differently: count, do not fail silently)
             bad += 1; print('CROPBOX', (w, h), a, b)
     n_exp += int(keep.sum())
-print(f'ref_diff_fuzz seed {seed}: 6001 partition lengths, {n_sizes} pyramid sizes, {n_masks} masks (+ vectorised), '
+print(f'fuzz_ref_diff seed {seed}: 6001 partition lengths, {n_sizes} pyramid sizes, {n_masks} masks (+ vectorised), '
       f'{n_exp} expanded boxes: {bad} mismatches')
 sys.exit(1 if bad else 0)
