@@ -434,7 +434,10 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
       A((void**)&l.fc_bf, F * 4);
     }
   }
-  h->stage_elems = std::max<size_t>(std::max<size_t>(C * h->kpatch, F * C), std::max<size_t>(3 * C * C, L * C));
+  // (every tensor that goes through the fp32 staging buffer: conv1, c_fc / c_proj, in_proj, the positional
+  // embedding and the output projection — C x E exceeds the others on a narrow tower with a wide embedding)
+  h->stage_elems = std::max<size_t>(std::max<size_t>(C * h->kpatch, F * C),
+                                    std::max<size_t>(std::max<size_t>(3 * C * C, L * C), C * E));
   A((void**)&h->stage, h->stage_elems * 4);
   // workspace
   if (!text) A(&h->a_patch, B * h->p2 * h->kpatch * e16());

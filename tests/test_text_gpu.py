@@ -33,6 +33,18 @@ def test_encode_text_tiny(cuda, dtype, tol, n, length):
     _check(out, ref, tol)
 
 
+def test_narrow_tower_with_a_wide_embedding(cuda):
+    """width 64, embed 464: text_projection (64 x 464) is the largest tensor that goes through the fp32 staging
+    buffer of the weight upload — it used to be sized for conv1 / MLP / in_proj / positional embedding only
+    (found by tests/fuzz_text.py)."""
+    arch = dict(context=20, vocab=807, width=64, layers=1, heads=1, mlp_dim=64, embed_dim=464)
+    sd = synthetic_text_state_dict(**arch)
+    model, _ = clip.load(sd, max_batch=16)
+    tok = synthetic_tokens(21, 5, arch['vocab'], seed=3)
+    ref = l2_normalize(encode_text_ref(sd, TextConfig(**arch), tok))
+    _check(model.encode_text(tok.to(cuda), normalize=True, out_dtype=torch.float32), ref, 1e-3)
+
+
 def test_encode_text_clip_b32_text_tower(cuda):
     """The real text architecture (77 x 512, 8 heads, 12 layers, vocab 49408) at 30 prompts = 2310 rows."""
     sd = synthetic_text_state_dict()
