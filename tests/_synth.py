@@ -50,8 +50,8 @@ def make_coco(root: pathlib.Path, sizes, proposals_per_image: int = 12, seed: in
         n = proposals_per_image
         x1 = rng.uniform(0, w * 0.7, n)
         y1 = rng.uniform(0, h * 0.7, n)
-        bw = rng.uniform(2, w * 0.5, n)
-        bh = rng.uniform(2, h * 0.5, n)
+        bw = rng.uniform(2, max(w * 0.5, 2.5), n)
+        bh = rng.uniform(2, max(h * 0.5, 2.5), n)
         score = np.sort(rng.uniform(0, 1, n))[::-1]
         props.append(np.stack([x1, y1, np.minimum(x1 + bw, w), np.minimum(y1 + bh, h), score], 1).astype(np.float32))
     pkl = root / 'proposals.pkl'
