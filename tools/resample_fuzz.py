@@ -14,7 +14,8 @@ from oadp_amd.weights import synthetic_state_dict
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
-model, _ = clip.load(synthetic_state_dict(image_size=224, patch_size=32, width=128, layers=1, heads=2, mlp_dim=256,
+OUT = int(os.environ.get('OUT_SIZE', 224))  # the model's input resolution = the crop size (a multiple of 32)
+model, _ = clip.load(synthetic_state_dict(image_size=OUT, patch_size=32, width=128, layers=1, heads=2, mlp_dim=256,
                                           embed_dim=64), max_batch=2)
 vis = model.visual
 dev = torch.device('cuda:0')
@@ -50,7 +51,7 @@ for it in range(n):
             continue
         boxes.append((float(np.float32(x1)), float(np.float32(y1)), float(np.float32(x2)), float(np.float32(y2))))
     for squash in (False, True):
-        host = Preprocess(224, squash=squash)
+        host = Preprocess(OUT, squash=squash)
         try:
             out = vis.crop_resize_normalize_batch([d], [boxes], squash=squash, out_dtype=torch.float32)
         except Exception as e:  # (e.g. a Resize that would exceed the supported size: must be loud, not wrong)
@@ -76,5 +77,5 @@ for it in range(n):
     if not np.array_equal(got, ref):
         bad += 1
         print('MISMATCH resize', (w, h), '->', (ow, oh), 'max', int(np.abs(got.astype(int) - ref).max()))
-print(f'resample_fuzz seed {seed}: {n} images, {crops} crops and {resizes} resizes compared with PIL, {bad} mismatches')
+print(f'resample_fuzz seed {seed} (out {OUT}): {n} images, {crops} crops and {resizes} resizes compared with PIL, {bad} mismatches')
 sys.exit(1 if bad else 0)
