@@ -13,13 +13,14 @@ from oadp_amd.weights import synthetic_state_dict
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
-model, pre = clip.load(synthetic_state_dict(image_size=224, patch_size=32, width=128, layers=1, heads=2, mlp_dim=256,
+R, S, RESCALE = (lambda t: (int(t[0]), int(t[1]), float(t[2])))(os.environ.get('BLOCK', '224,112,1.5').split(','))
+model, pre = clip.load(synthetic_state_dict(image_size=R, patch_size=32, width=128, layers=1, heads=2, mlp_dim=256,
                                             embed_dim=64), max_batch=2)
 ds = blocks.Dataset.__new__(blocks.Dataset)
-ds._r, ds._s, ds._rescale = 224, 112, 1.5
+ds._r, ds._s, ds._rescale = R, S, RESCALE
 ds.transform = pre
 dev = torch.device('cuda:0')
-EDGE = [223, 224, 225, 335, 336, 337, 448, 449, 504, 505]
+EDGE = [R - 1, R, R + 1, R + S - 1, R + S, R + S + 1, 2 * R, 2 * R + 1, int(R * RESCALE), int(R * RESCALE) + 1]
 bad = crops = 0
 i = 0
 while i < n:
@@ -29,8 +30,8 @@ while i < n:
         w = int(rng.choice(EDGE)) if rng.random() < 0.25 else int(rng.integers(1, 1500))
         h = int(rng.choice(EDGE)) if rng.random() < 0.25 else int(rng.integers(1, 1100))
         arrs.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
-    out, counts = model.visual.blocks_batch([torch.from_numpy(a).to(dev) for a in arrs], block_size=224,
-                                            max_stride=112, rescale=1.5, out_dtype=torch.float32)
+    out, counts = model.visual.blocks_batch([torch.from_numpy(a).to(dev) for a in arrs], block_size=R,
+                                            max_stride=S, rescale=RESCALE, out_dtype=torch.float32)
     out = out.cpu()
     i0 = 0
     for a, c in zip(arrs, counts):
@@ -46,5 +47,5 @@ while i < n:
         crops += c
         i0 += c
     i += k
-print(f'blocks_fuzz seed {seed}: {i} images, {crops} crops compared with the host (PIL) dataset, {bad} mismatches')
+print(f'blocks_fuzz seed {seed} (block {R}, stride {S}, rescale {RESCALE}): {i} images, {crops} crops compared with the host (PIL) dataset, {bad} mismatches')
 sys.exit(1 if bad else 0)
