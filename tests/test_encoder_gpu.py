@@ -328,3 +328,36 @@ def test_encode_image_clip_like_weight_statistics(cuda, dtype, tol):
     _check(out, ref, tol, tol)
     small = model.encode_image(x[:5].to(cuda), normalize=True, out_dtype=torch.float32)  # non-persistent kernels
     _check(small, ref[:5], tol, tol)
+
+
+def test_two_handles_on_two_host_threads(cuda):
+    """A handle is not thread-safe, but distinct handles may be driven from distinct host threads (ctypes drops
+    the GIL inside the library): two models with different weights encode different batches on their own HIP
+    streams at the same time, twenty rounds each — every result equals the one computed alone."""
+    import threading
+    sds = [synthetic_state_dict(seed=s, **TINY) for s in (1, 2)]
+    models = [clip.load(sd, max_batch=40)[0] for sd in sds]
+    xs = [synthetic_images(n, seed=50 + n).to(cuda) for n in (37, 64)]
+    alone = [m.encode_image(x, normalize=True, out_dtype=torch.float32).clone() for m, x in zip(models, xs)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream(cuda)
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    out = models[i].encode_image(xs[i], normalize=True, out_dtype=torch.float32)
+                    stream.synchronize()
+                    if not torch.equal(out, alone[i]):
+                        errors.append(f'thread {i}: result differs')
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f'thread {i}: {e!r}')
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
