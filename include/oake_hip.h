@@ -31,8 +31,8 @@
  * passed as `stream` (an opaque void* here so the header needs no HIP include; 0 = the
  * null stream).  A handle is bound to one device, owns weights + workspace, and is not
  * thread-safe (the reference runs one process per GPU and calls the model only from the
- * main thread: oadp/oake/base.py:122-126); distinct handles may be driven from distinct host
- * threads, tests/test_encoder_gpu.py::test_two_handles_on_two_host_threads).
+ * main thread: oadp/oake/base.py:122-126).  Distinct handles may be driven from distinct host
+ * threads (tests/test_encoder_gpu.py::test_two_handles_on_two_host_threads).
  */
 #ifndef OAKE_HIP_H_
 #define OAKE_HIP_H_
