@@ -695,9 +695,24 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   const bool direct = h->patch_direct && in_dtype == h->dt16 && h->xdt != DT_F32 &&
                       gemm_patch_direct_ok(c.image_size, c.patch_size, c.stride, c.padding, a.M, a.N, a.K, &h->opts) &&
                       reinterpret_cast<uintptr_t>(imgs) % 16 == 0;
+  // ... and where the convolution pads or its stride cuts patches (objects mode: stride 16, padding 15), from a
+  // zero-padded 16-bit copy of the batch in the a_patch buffer: a third of the im2col matrix's bytes, written
+  // once, the overlapping patches re-read from the L2
+  const int hp = c.image_size + 2 * c.padding;             // rows per padded plane
+  const int ws = (c.image_size + 2 * c.padding + 7) & ~7;  // padded row stride (pixels)
+  const bool padded = !direct && h->patch_direct && h->xdt != DT_F32 &&
+                      (c.stride != c.patch_size || c.padding != 0) &&  // (plain geometry, other input type: im2col is the cheaper cast)
+                      gemm_patch_padded_ok(c.patch_size, c.stride, a.M, a.N, a.K, &h->opts) &&
+                      (h->grid - 1) * c.stride + c.patch_size <= hp &&
+                      (size_t)3 * hp * ws <= (size_t)h->p2 * h->kpatch;  // fits the im2col buffer
   if (direct) {
     a.A = imgs;
     a.patch_S = c.image_size; a.patch_P = c.patch_size; a.patch_G = h->grid;
+  } else if (padded) {
+    RUN(h, s, "pad_nchw", 0.0, (double)nb * 3 * hp * ws * 2 + (double)nb * 3 * c.image_size * c.image_size * in_es,
+        launch_pad_nchw(h->dt16, imgs, in_dtype, h->a_patch, nb, c.image_size, c.padding, hp, ws, s));
+    a.A = h->a_patch;
+    a.patch_S = ws; a.patch_H = hp; a.patch_P = c.patch_size; a.patch_T = c.stride; a.patch_G = h->grid;
   } else {
     const double im_bytes = (double)nb * h->p2 * h->kpatch * 2 + (double)nb * 3 * c.image_size * c.image_size * in_es;
     RUN(h, s, "im2col", 0.0, im_bytes,

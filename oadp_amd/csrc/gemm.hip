@@ -59,6 +59,7 @@ struct EpiParams {
   int nparts;
   float inv_k;            // 1 / K
   int patch_S, patch_P, patch_G;  // A = NCHW image batch, gathered patch-wise (GemmArgs::patch_*); 0 = matrix
+  int patch_T, patch_H;           // patch stride and rows per colour plane (0: = patch_P / patch_S, the unpadded form)
 };
 constexpr int kRowParts = 16;  // float2 slots per row (128 B): N <= 1024 residual width
 
@@ -134,7 +135,7 @@ __device__ __forceinline__ void tile_origin(const TileMap& tmap, int t, int BM, 
 template <typename T, int BM, int TN, bool PAIRED>
 __device__ __forceinline__ const char* piece_src(const T* A, const T* W, int M, int N, int K, int m0,
                                                  int n0, int ii, int lane, int pS = 0, int pP = 0,
-                                                 int pG = 0) {
+                                                 int pG = 0, int pT = 0, int pH = 0) {
   const int rr = 8 * ii + (lane >> 3);
   const int chunk = (lane & 7) ^ ((rr >> 1) & 7);
   if (rr < BM) {
@@ -144,7 +145,9 @@ __device__ __forceinline__ const char* piece_src(const T* A, const T* W, int M, 
       const int img = gr / (pG * pG), p = gr - img * pG * pG;
       const int py = p / pG, px = p - py * pG;
       const int ky = (chunk * 8) / pP, kx = (chunk * 8) - ky * pP;
-      return reinterpret_cast<const char*>(A + (size_t)img * 3 * pS * pS + (size_t)(py * pP + ky) * pS + px * pP + kx);
+      // (pS = row stride, pH = rows per plane, pT = distance between patch origins: a zero-padded buffer lets
+      // overlapping / offset patches — objects mode: stride 16, padding 15 — take the same path)
+      return reinterpret_cast<const char*>(A + (size_t)img * 3 * pH * pS + (size_t)(py * pT + ky) * pS + px * pT + kx);
     }
     return reinterpret_cast<const char*>(A + (size_t)gr * K) + chunk * 16;
   }
@@ -155,10 +158,10 @@ __device__ __forceinline__ const char* piece_src(const T* A, const T* W, int M, 
 }
 
 // byte offset of K-tile kt in the patch-gather form: channel kt*64 / P^2, pixel row (kt*64 % P^2) / P
-__device__ __forceinline__ size_t patch_koff(int kt, int pS, int pP) {
+__device__ __forceinline__ size_t patch_koff(int kt, int pS, int pP, int pH) {
   const int k0 = kt * BK, pp = pP * pP;
   const int ch = k0 / pp, ky0 = (k0 - ch * pp) / pP;
-  return ((size_t)ch * pS * pS + (size_t)ky0 * pS) * 2;
+  return ((size_t)ch * pH * pS + (size_t)ky0 * pS) * 2;
 }
 
 // Wave-level epilogue.  mbase = first row of the lane (m0 + wm*TM + lane&15), nwave = first column
@@ -901,7 +904,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 #pragma unroll
       for (int j = 0; j < NPL; ++j)
         src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane, ep.patch_S,
-                                              ep.patch_P, ep.patch_G);
+                                              ep.patch_P, ep.patch_G, ep.patch_T, ep.patch_H);
     };
     // pieces lw + NL j with j < kAPieces are A rows for every DMA wave (BM / 8 is a multiple of NL)
     static_assert((BM / 8) % NL == 0, "A pieces split evenly over the DMA waves");
@@ -941,7 +944,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     if (s_g < total) {                                                                       \
       char* _base = smem + s_buf * kStageBytes;                                              \
       const size_t _koff = (size_t)s_kt * (BK * 2);                                          \
-      const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P) : _koff; \
+      const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P, ep.patch_H) : _koff; \
       _Pragma("unroll") for (int _j = (j0_); _j < (j1_); ++_j)                               \
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
                                            (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0); \
@@ -1305,7 +1308,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
       for (int j = 0; j < NPL; ++j)
         src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane, ep.patch_S,
-                                              ep.patch_P, ep.patch_G);
+                                              ep.patch_P, ep.patch_G, ep.patch_T, ep.patch_H);
     };
     int s_kt = 0, s_tile = 0;  // producer cursor: K-tile s_kt of tile s_tile goes to slot (flat index) & 1
     int d_kt = 0, d_tile = 0;  // the K-tile the compute waves work on
@@ -1313,7 +1316,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   do {                                                                                           \
     char* _base = smem + (buf_) * kStageBytes;                                                   \
     const size_t _koff = (size_t)s_kt * (BK * 2);                                                \
-    const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P) : _koff;    \
+    const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P, ep.patch_H) : _koff;    \
     _Pragma("unroll") for (int _j = 0; _j < NPL; ++_j)                                           \
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
                                          (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0);  \
@@ -1612,6 +1615,7 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   if (a.patch_S != 0) {
     if (EPI != EPI_PATCH16 && EPI != EPI_PATCH) return hipErrorInvalidValue;
     ep.patch_S = a.patch_S; ep.patch_P = a.patch_P; ep.patch_G = a.patch_G;
+    ep.patch_T = a.patch_T ? a.patch_T : a.patch_P; ep.patch_H = a.patch_H ? a.patch_H : a.patch_S;
   }
   OAKE_LAUNCH(kern, dim3(grid), dim3((WM * WN + 4) * 64), lds, s,
                      reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M, a.N,
@@ -1654,6 +1658,7 @@ hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
   if (a.patch_S != 0) {
     if (EPI != EPI_PATCH16 && EPI != EPI_PATCH) return hipErrorInvalidValue;
     ep.patch_S = a.patch_S; ep.patch_P = a.patch_P; ep.patch_G = a.patch_G;
+    ep.patch_T = a.patch_T ? a.patch_T : a.patch_P; ep.patch_H = a.patch_H ? a.patch_H : a.patch_S;
   }
   OAKE_LAUNCH(kern, dim3(grid), dim3(512), lds, s, reinterpret_cast<const T*>(a.A),
               reinterpret_cast<const T*>(a.W), a.M, a.N, a.K, ep, tmap);
@@ -1758,6 +1763,13 @@ bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, 
   return stride == patch && padding == 0 && image % patch == 0 && patch % 8 == 0 && BK % patch == 0 &&
          (patch * patch) % BK == 0 && image % 8 == 0 && K == 3 * patch * patch &&
          gemm_uses_persistent(M, N, K, opts);
+}
+
+bool gemm_patch_padded_ok(int patch, int stride, int M, int N, int K, const LaunchOpts* opts) {
+  // as gemm_patch_direct_ok, for patches read from a zero-padded buffer with 16-byte-aligned rows: the patch
+  // origins (multiples of the stride) and the 8-pixel chunks must stay 16-byte aligned
+  return patch % 8 == 0 && stride % 8 == 0 && BK % patch == 0 && (patch * patch) % BK == 0 &&
+         K == 3 * patch * patch && gemm_uses_persistent(M, N, K, opts);
 }
 
 hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s) {

@@ -64,10 +64,15 @@ struct GemmArgs {
   // im2col matrix, column k = (channel, ky, kx); the DMA waves gather the patch rows straight from the
   // images (8 pixels = 16 B per lane, source-side swizzle as for a matrix).  patch_S == 0: plain matrix A.
   int patch_S, patch_P, patch_G;
+  // the general form: A = a zero-padded 16-bit buffer [n,3,patch_H,patch_S] (patch_S = row stride in pixels, a
+  // multiple of 8), patch origins patch_T pixels apart (0: patch_T = patch_P, patch_H = patch_S, i.e. the above)
+  int patch_T, patch_H;
 };
 // true when the conv1 GEMM can read its A operand straight from the NCHW batch (no im2col pass)
 bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,
                           const LaunchOpts* opts = nullptr);
+// ... or from a zero-padded copy of it (strides that cut patches, padding: objects mode)
+bool gemm_patch_padded_ok(int patch, int stride, int M, int N, int K, const LaunchOpts* opts = nullptr);
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
 // true when launch_gemm runs this shape on the persistent kernel (row statistics via rowpart_*)
@@ -109,6 +114,11 @@ hipError_t launch_gather_eot(const int32_t* tokens, const void* x, int x_dtype, 
 // im2col of NCHW images into the conv1 GEMM A operand [n*G*G, 3*P*P] (16-bit).
 hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, int n, int image,
                          int patch, int stride, int pad, int grid, hipStream_t s);
+
+// zero-padded 16-bit copy [n,3,hp,ws] of an NCHW batch (image at (pad, pad); ws = row stride, a multiple of 8):
+// what the conv1 GEMM gathers its patches from when the convolution pads or its stride cuts patches
+hipError_t launch_pad_nchw(int dtype16, const void* img, int in_dtype, void* out, int n, int image, int pad, int hp,
+                           int ws, hipStream_t s);
 
 // ---- attention ---------------------------------------------------------------------------
 // qkv [n*L, 3*H*64] 16-bit (q pre-scaled by 1/8) -> out [n*L, H*64] 16-bit. Full self-attention.

@@ -361,3 +361,39 @@ def test_two_handles_on_two_host_threads(cuda):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize('in_dtype', [torch.float16, torch.float32])
+def test_objects_conv1_from_padded_buffer_equals_im2col(cuda, in_dtype):
+    """Objects mode's conv1 (patch 32, stride 16, padding 15: overlapping patches, zero border) gathered by the
+    GEMM from a zero-padded 16-bit copy of the batch vs the same GEMM on the im2col matrix: the same operand
+    bits in the same order => bit-identical features; fp32 inputs (cast in the pad pass) included.  70 crops =
+    13 720 patch rows: ragged last tile, several tiles per persistent block."""
+    sd = synthetic_state_dict()
+
+    def make(patch_direct):
+        model, _ = clip.load(sd, max_batch=70)
+        v = model.visual
+        v.positional_embedding = v.interpolate_positional_embedding((14, 14))
+        v.grid = 14
+        v.conv1.stride = (16, 16)
+        v.conv1.padding = (15, 15)
+        v.object_stream = True
+        v.set_option('patch_direct', patch_direct)
+        return v
+
+    a, b = make(1), make(0)
+    x = synthetic_images(70, seed=12).to(in_dtype).to(cuda)
+    masks = (torch.rand(70, 1, 14, 14, generator=torch.Generator().manual_seed(3)) < 0.6).half().to(cuda)
+    ya = a(x, masks, normalize=True, out_dtype=torch.float32)
+    yb = b(x, masks, normalize=True, out_dtype=torch.float32)
+    assert torch.equal(ya, yb)
+    a.profile(True)
+    a(x, masks)
+    names = {p_['name'] for p_ in a.profile_read()}
+    a.profile(False)
+    assert 'im2col' not in names and 'pad_nchw' in names and 'gemm_conv1' in names
+    sd2 = dict(sd)
+    sd2['visual.positional_embedding'] = a.positional_embedding.detach().cpu().float()
+    ref = l2_normalize(encode_objects_ref(sd2, ViTConfig(stride=16, padding=15), x[:4].cpu().float(), masks[:4].cpu().float()))
+    _check(ya[:4], ref, 1e-3, 1e-3)
