@@ -23,7 +23,7 @@ if (src / 'session.txt').exists():
     session = (src / 'session.txt').read_text().splitlines()[0].split(':', 1)[1].strip()
 
 # profiler slot name <- kernel-name fragment (the residual GEMM instantiation serves out_proj and c_proj)
-NAMES = {'im2col_kernel': 'im2col', 'gemm_pp_kernelIDF16_Li6E': 'gemm_conv1', 'gemm_pp_kernelIDF16_Li7E': 'gemm_qkv',
+NAMES = {'im2col_kernel': 'im2col', 'pad_nchw_kernel': 'pad_nchw', 'gemm_pp_kernelIDF16_Li6E': 'gemm_conv1', 'gemm_pp_kernelIDF16_Li7E': 'gemm_qkv',
          'gemm_pp_kernelIDF16_Li8E': 'gemm_c_fc', 'gemm_pp_kernelIDF16_Li5E': 'gemm_resid16(out_proj+c_proj)',
          'attention_pair_kernelIDF16_': 'attention', 'attention_coop_kernelIDF16_': 'attention',
          'embed_ln_pre_kernel': 'embed_ln_pre', 'crop_normalize_jobs_kernel': 'crop_normalize',
