@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OAKE_ABI_VERSION 2
+#define OAKE_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define OAKE_API __attribute__((visibility("default")))
@@ -272,77 +272,26 @@ OAKE_API int oake_jpeg_reconstruct(oake_handle* h, const uint8_t* h_data, size_t
  * Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
  * enable=1 brackets every kernel launch with events; oake_profile_read synchronises and
  * returns, for up to `cap` kernel slots, name / total milliseconds / launch count / flops.
- * Profiling serialises launches — never leave it on inside a throughput measurement.
+ * enable=S > 1 stamps only every S-th launch (counted over all kernels since the call): a stamped
+ * launch ends with a completion signal and a cache write-back that the kernel after it pays for, so
+ * with every launch stamped the durations add up to more than an un-instrumented step takes; sampled
+ * sparsely over S steps (S not dividing the launches per step) every launch position is stamped once,
+ * each behind un-instrumented predecessors.  `launches` counts the stamped launches (what total_ms,
+ * flops and bytes cover), `seen` all launches since the reset.
+ * Profiling perturbs launches — never leave it on inside a throughput measurement.
  */
 typedef struct oake_profile_entry {
   char name[48];
   double total_ms;
   double flops;      /* algorithmic FLOPs summed over the launches (2 per MAC), 0 for non-GEMM */
   double bytes;      /* algorithmic bytes summed over the launches (HBM-bound kernels) */
-  int64_t launches;
+  int64_t launches;  /* stamped launches */
+  int64_t seen;      /* all launches since oake_profile_reset */
 } oake_profile_entry;
 
 OAKE_API int oake_profile_enable(oake_handle* h, int enable);
 OAKE_API int oake_profile_read(oake_handle* h, oake_profile_entry* entries, int cap, int* count);
 OAKE_API int oake_profile_reset(oake_handle* h);
-
-/*
- * Kernel-level debug/test entry points (used by tests/ to check each kernel against the
- * oracle; not needed by a reference-side integration).  All pointers are device pointers.
- * dtype16 = OAKE_F16 | OAKE_BF16 selects the 16-bit operand type.
- */
-/* C[m,n] = A[m,k] * W[n,k]^T + bias[n] (fp32 out).  A, W are 16-bit row-major. */
-OAKE_API int oake_debug_gemm(const void* d_a, const void* d_w, const float* d_bias, float* d_c,
-                    int m, int n, int k, int dtype16, void* stream);
-/* C16[m,n] = (quick_gelu?)(A * W^T + bias) stored in the 16-bit operand type (n % 8 == 0). */
-OAKE_API int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_bias, void* d_c,
-                      int m, int n, int k, int dtype16, int gelu, void* stream);
-/* C16[m,n] = (quick_gelu?)(LayerNorm(x)[m,k] * W^T + bias) with the LayerNorm folded into the GEMM
- * (gamma into W, beta into bias, per-row statistics applied in the epilogue); x is 16-bit [m,k],
- * W fp32 [n,k].  Synchronous (allocates temporaries). */
-OAKE_API int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gamma,
-                         const float* d_beta, const float* d_bias, void* d_c, int m, int n, int k,
-                         int dtype16, int gelu, void* stream);
-/* y = LayerNorm(x) over last dim `c` (eps 1e-5), x [rows,c] of x_dtype (OAKE_F32 or dtype16)
- * -> y 16-bit [rows,c]. */
-OAKE_API int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, const float* d_beta,
-                         void* d_y, int rows, int c, int dtype16, void* stream);
-/* Multi-head self-attention on packed qkv [n*l, 3*heads*64] (q pre-scaled), -> [n*l, heads*64]. */
-OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads,
-                         int dtype16, void* stream);
-/* Raw ds_read_b64_tr_b16 semantics probe: in = 256 uint16, out = 64 lanes x 4 uint16. */
-OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
-/* Measurement: a register-only MFMA stream (two waves per SIMD on every CU, `iters` x 20
- * v_mfma_f32_16x16x32_f16 per wave, no LDS or memory traffic) on the 9 x 64 x 8 f16 operand fragments at
- * d_frags16; *flop (host, may be NULL) receives the FLOPs of the launch.  Timed by the caller, it gives the
- * matrix rate the board sustains under its power cap for that operand data (bench.py `roofline.sustained`). */
-OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream);
-/* Attention variant bits: 1 = ds_read_b64_tr_b16 V fragments (else 16-bit LDS gathers),
- * 2 = 32 queries per wave (else 64), 4 = sequences longer than 64 keys share K / V through LDS between
- * the four waves of a block, 8 = objects mode: the object token's attention rides on an idle wave
- * of that kernel, 16 = sequences of at most 64 keys without a causal mask: the two waves of a (crop,
- * head) share its K / V in LDS, staged with LDS-DMA, 32 = sequences longer than 128 keys: one block of
- * eight waves per (crop, head) reads K / V once (else two blocks of four read them twice; measured slower,
- * so not in the default), 64 = sequences of 65..208 keys: the whole K / V of a (crop, head) is brought into
- * LDS up front with LDS-DMA and the key loop runs without barriers or global accesses (measured equal, so not
- * in the default either).  Default 31. */
-OAKE_API int oake_debug_set_attention_variant(int variant);
-/* GEMM configuration: -1 = automatic per shape, 0..11 = forced (see csrc/gemm.hip).
- * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel
- * entry points of the calling thread; a handle's own switches are set with oake_set_option. */
-OAKE_API int oake_debug_set_gemm_variant(int variant);
-/* x[m,n] (16-bit, in place) += A * W^T + bias — the residual epilogue of out_proj / c_proj.  On the
- * persistent kernel (large m) d_rowpart [m, 16, 2] fp32 (or NULL) receives (sum, sum of squares) of
- * every 64-column slice of each output row (the LayerNorm statistics handed to the next GEMM). */
-OAKE_API int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const float* d_bias, void* d_x,
-                            float* d_rowpart, int m, int n, int k, int dtype16, void* stream);
-/* GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside), n < 0 = M slabs of
- * -n tiles (column-major inside). */
-OAKE_API int oake_debug_set_gemm_panel(int panel);
-/* Debug: device buffer of 4608 uint64 receiving per-tile cycle stamps of the production GEMM
- * (entry, tile start, epilogue start, epilogue end; then per-block wall-clock entry/exit), or NULL. */
-OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
-
 
 /*
  * Per-handle switches (nothing process-wide: two handles / lanes never see each other's settings).
@@ -351,8 +300,10 @@ OAKE_API int oake_debug_set_gemm_trace(void* d_trace);
  *                               that block for one row per image.  0 = run the block for every token as
  *                               the reference does (A/B runs, tests).  Default 1.
  *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default), 0..11 forced (csrc/gemm.hip)
- *   OAKE_OPT_GEMM_PANEL         GEMM tile order, as oake_debug_set_gemm_panel.  Default 0.
- *   OAKE_OPT_ATTENTION_VARIANT  bit set, as oake_debug_set_attention_variant.  Default 31.
+ *   OAKE_OPT_GEMM_PANEL         GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside),
+ *                               n < 0 = M slabs of -n tiles (column-major inside).  Default 0.
+ *   OAKE_OPT_ATTENTION_VARIANT  bit set of attention kernel forms (documented with
+ *                               oake_debug_set_attention_variant, oake_hip_debug.h).  Default 31.
  *   OAKE_OPT_PATCH_DIRECT       conv1 gathers its patch rows straight from a 16-bit NCHW input batch (no
  *                               im2col pass) where the geometry allows it.  0 = always im2col.  Default 1.
  */
@@ -366,12 +317,6 @@ enum {
 OAKE_API int oake_set_option(oake_handle* h, int option, int value);
 OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);
 
-/* Test hook: copy a 16-bit matmul weight back from the device, as uploaded (f32 -> 16 bit; q rows of
- * in_proj scaled by 1/8; visual.proj / text_projection transposed to [embed, width]).  `name` is the
- * state-dict key ("visual.conv1.weight", "...attn.in_proj_weight", "...attn.out_proj.weight",
- * "...mlp.c_fc.weight", "...mlp.c_proj.weight", "visual.proj"); "<key>#folded" reads the gamma-folded
- * copy of in_proj / c_fc.  numel must match the tensor. */
-OAKE_API int oake_debug_read_weight16(oake_handle* h, const char* name, uint16_t* h_out, size_t numel);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ OAKE_ERR_INVALID, OAKE_ERR_HIP, OAKE_ERR_STATE, OAKE_ERR_UNKNOWN_TENSOR, OAKE_ER
 OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
 OAKE_OPT_CLS_LAST, OAKE_OPT_GEMM_VARIANT, OAKE_OPT_GEMM_PANEL, OAKE_OPT_ATTENTION_VARIANT = 1, 2, 3, 4
 OAKE_OPT_PATCH_DIRECT = 5
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library
 LIB_PATH = pathlib.Path(os.environ.get('OAKE_LIB') or pathlib.Path(__file__).resolve().parent / 'liboake_hip.so')
@@ -25,7 +25,7 @@ class OakeConfig(C.Structure):
 
 class ProfileEntry(C.Structure):
     _fields_ = [('name', C.c_char * 48), ('total_ms', C.c_double), ('flops', C.c_double),
-                ('bytes', C.c_double), ('launches', C.c_int64)]
+                ('bytes', C.c_double), ('launches', C.c_int64), ('seen', C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/oake_hip.h declares
@@ -64,6 +64,13 @@ SIGNATURES = {
     'oake_profile_enable': (_I, [_VP, _I]),
     'oake_profile_read': (_I, [_VP, C.POINTER(ProfileEntry), _I, C.POINTER(_I)]),
     'oake_profile_reset': (_I, [_VP]),
+    'oake_set_option': (_I, [_VP, _I, _I]),
+    'oake_get_option': (_I, [_VP, _I, C.POINTER(_I)]),
+}
+
+# include/oake_hip_debug.h: kernel-level test / measurement entry points (tests/, tools/, bench.py's power
+# probe) — exported by the same library, not part of the reference-facing ABI above
+DEBUG_SIGNATURES = {
     'oake_debug_gemm': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_gemm16': (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     'oake_debug_ln_gemm16': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
@@ -76,8 +83,6 @@ SIGNATURES = {
     'oake_debug_gemm_resid16': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_set_gemm_panel': (_I, [_I]),
     'oake_debug_set_gemm_trace': (_I, [_VP]),
-    'oake_set_option': (_I, [_VP, _I, _I]),
-    'oake_get_option': (_I, [_VP, _I, C.POINTER(_I)]),
     'oake_debug_read_weight16': (_I, [_VP, C.c_char_p, _VP, C.c_size_t]),
 }
 
@@ -101,7 +106,7 @@ def load() -> C.CDLL:
             f'{LIB_PATH} not found: build it with `python -m oadp_amd.build` '
             '(or __graft_entry__.build()); there is no CPU fallback')
     lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_LOCAL)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args

@@ -19,7 +19,7 @@ CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
 SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
-HEADERS = ['common.h', 'kernels.h', '../../include/oake_hip.h']
+HEADERS = ['common.h', 'kernels.h', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'
 FLAGS = [
     f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',

@@ -567,7 +567,8 @@ class VisionTransformer(_HookPoint):
         return out
 
     # -- profiler (bench.py) ---------------------------------------------------------------
-    def profile(self, enable: bool) -> None:
+    def profile(self, enable: bool | int) -> None:
+        """``True`` / 1: stamp every launch; an int S > 1: every S-th launch only (``oake_profile_enable``)."""
         if self._handle is None:
             raise RuntimeError('run one forward before enabling the profiler')
         self._lib.oake_profile_reset(self._handle)
@@ -579,7 +580,7 @@ class VisionTransformer(_HookPoint):
         _lib.check(self._lib, self._handle,
                    self._lib.oake_profile_read(self._handle, buf, 64, C.byref(n)), 'profile_read')
         return [dict(name=buf[i].name.decode(), total_ms=buf[i].total_ms, flops=buf[i].flops,
-                     bytes=buf[i].bytes, launches=buf[i].launches) for i in range(min(n.value, 64))]
+                     bytes=buf[i].bytes, launches=buf[i].launches, seen=buf[i].seen) for i in range(min(n.value, 64))]
 
 
 class TextTransformer:

@@ -8,8 +8,40 @@ Compose-like object with ``.transforms`` so ``dataset.transform = preprocess`` a
 from __future__ import annotations
 
 import numpy as np
+import PIL
 import PIL.Image
 import torch
+
+# The device resampler (csrc/resample.hip) restates Pillow's ImagingResample — fixed-point coefficients, uint8
+# intermediate, and the undocumented choice of which pass runs first for sources > 100x taller than wide — and is
+# pinned bit for bit against THIS Pillow release (tests/test_resample.py, oracle/resample_ref.py).  With another
+# release the device path is still a correct antialiased bicubic resampler, but "bit-identical to the host PIL
+# path" is only known for the release below: `check_pillow_version` says so once instead of staying silent.
+PILLOW_PINNED = (12, 2)
+_pillow_warned = False
+
+
+def check_pillow_version(version: str | None = None) -> bool:
+    """True if the installed Pillow is the release the device resampler was pinned against; otherwise warn
+    (once per process) and return False.  Called when a dataset enables ``device_preprocess``."""
+    global _pillow_warned
+    import warnings
+    version = version or PIL.__version__
+    try:
+        got = tuple(int(x) for x in version.split('.')[:2])
+    except ValueError:
+        got = ()
+    if got == PILLOW_PINNED:
+        return True
+    if not _pillow_warned:
+        _pillow_warned = True
+        warnings.warn(
+            f'Pillow {version} is installed; the GPU crop/resize path is pinned bit-exactly against Pillow '
+            f'{PILLOW_PINNED[0]}.{PILLOW_PINNED[1]} (fixed-point bicubic + pass order). Features may differ in the '
+            'last bit from the host PIL path under this release; run tests/test_resample.py to re-pin, or use '
+            'device_preprocess=False for the reference\'s own PIL transform.', RuntimeWarning, stacklevel=2)
+    return False
+
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/oake_hip.h"
+#include "../../include/oake_hip_debug.h"
 #include "kernels.h"
 
 namespace oake {
@@ -53,7 +54,8 @@ struct LayerW {
 struct ProfSlot {
   std::string name;
   double flops = 0, bytes = 0;
-  int64_t launches = 0;
+  int64_t launches = 0;  // stamped launches (what ms / flops / bytes cover)
+  int64_t seen = 0;      // all launches since the reset
   double ms = 0;
 };
 
@@ -130,8 +132,12 @@ struct oake_handle {
   size_t jp_host_cap = 0, jp_coefs_cap = 0, jp_planes_cap = 0;
   hipEvent_t jp_copied = nullptr;  // the last upload out of jp_host has completed
 
-  // profiler
+  // profiler (prof_stride > 1: only every prof_stride-th launch is stamped — a stamped launch ends with the
+  // runtime's completion signal and cache write-back, which the NEXT kernel pays for; sampled sparsely, a
+  // stamped kernel runs behind un-instrumented predecessors, as in the throughput measurement)
   bool prof = false;
+  int prof_stride = 1;
+  int64_t prof_seq = 0;
   std::vector<ProfSlot> slots;
   std::vector<PendingEvt> pending;
   std::vector<hipEvent_t> evt_pool;
@@ -176,9 +182,15 @@ hipEvent_t get_evt(oake_handle* h) {
 }
 
 // RAII-less bracket: begin returns the index into pending (or -1 when profiling is off)
+bool prof_take(oake_handle* h, int sl) {
+  h->slots[sl].seen += 1;
+  return h->prof_seq++ % h->prof_stride == 0;
+}
+
 int prof_begin(oake_handle* h, const char* name, double flops, double bytes, hipStream_t s) {
   if (!h->prof) return -1;
   const int sl = slot_of(h, name);
+  if (!prof_take(h, sl)) return -1;
   h->slots[sl].flops += flops;
   h->slots[sl].bytes += bytes;
   h->slots[sl].launches += 1;
@@ -194,6 +206,7 @@ void prof_end(oake_handle* h, int idx, hipStream_t s) {
 int prof_begin_kernel(oake_handle* h, const char* name, double flops, double bytes) {
   if (!h->prof) return -1;
   const int sl = slot_of(h, name);
+  if (!prof_take(h, sl)) return -1;
   h->slots[sl].flops += flops;
   h->slots[sl].bytes += bytes;
   h->slots[sl].launches += 1;
@@ -1281,6 +1294,8 @@ int oake_blocks_batch(oake_handle* h, int n_images, const uint8_t* const* d_imag
     return fail(h, OAKE_ERR_INVALID, "null pointer");
   if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
     return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  if (reinterpret_cast<uintptr_t>(d_out) % 16 != 0)  // the crop kernels store 16-byte vectors
+    return fail(h, OAKE_ERR_INVALID, "d_out must be 16-byte aligned");
   for (int i = 0; i < n_images; ++i)
     if (!d_images[i] || heights[i] <= 0 || widths[i] <= 0) return fail(h, OAKE_ERR_INVALID, "bad image");
   HIP_TRY(h, hipSetDevice(h->device));
@@ -1553,6 +1568,8 @@ int oake_profile_enable(oake_handle* h, int enable) {
   if (!h) return OAKE_ERR_INVALID;
   if (!enable) prof_collect(h);
   h->prof = enable != 0;
+  h->prof_stride = enable > 1 ? enable : 1;
+  h->prof_seq = 0;
   return OAKE_OK;
 }
 
@@ -1576,6 +1593,7 @@ int oake_profile_read(oake_handle* h, oake_profile_entry* entries, int cap, int*
     entries[i].flops = h->slots[i].flops;
     entries[i].bytes = h->slots[i].bytes;
     entries[i].launches = h->slots[i].launches;
+    entries[i].seen = h->slots[i].seen;
   }
   return OAKE_OK;
 }

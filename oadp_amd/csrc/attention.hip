@@ -1226,14 +1226,9 @@ static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, i
 
 template <typename T>
 static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, int heads, hipStream_t s) {
-  static bool attr_set = false;
+  static DynLdsAttr attr;
   auto kern = attention_pair_kernel<T>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, pair_lds_bytes(64));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), pair_lds_bytes(64)); e != hipSuccess) return e;
   const int items = n * heads;
   OAKE_LAUNCH(kern, dim3((items + kPairItems - 1) / kPairItems), dim3(2 * kPairItems * 64),
                      pair_lds_bytes(L), s, reinterpret_cast<const T*>(qkv), reinterpret_cast<T*>(out), L,
@@ -1265,25 +1260,19 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
     const dim3 grid(((n_items + 7) / 8) * 8 * QG), blk(256);
     const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
     const int lds = full_lds_bytes(L, qkv_y != nullptr);
-    static bool attr16 = false, attrbf = false;
+    static DynLdsAttr attr16, attrbf;
     if (dtype16 == DT_F16) {
       auto kern = attention_full_kernel<f16_t>;
-      if (!attr16) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, full_lds_bytes(kFullMaxL, true) + 1024);
-        if (e != hipSuccess) return e;
-        attr16 = true;
-      }
+      if (hipError_t e = attr16.ensure(reinterpret_cast<const void*>(kern), full_lds_bytes(kFullMaxL, true) + 1024);
+          e != hipSuccess)
+        return e;
       OAKE_LAUNCH(kern, grid, blk, lds, s, reinterpret_cast<const f16_t*>(qkv), reinterpret_cast<f16_t*>(out), L,
                   heads, QG, causal, obj, n_items);
     } else if (dtype16 == DT_BF16) {
       auto kern = attention_full_kernel<bf16_t>;
-      if (!attrbf) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, full_lds_bytes(kFullMaxL, true) + 1024);
-        if (e != hipSuccess) return e;
-        attrbf = true;
-      }
+      if (hipError_t e = attrbf.ensure(reinterpret_cast<const void*>(kern), full_lds_bytes(kFullMaxL, true) + 1024);
+          e != hipSuccess)
+        return e;
       OAKE_LAUNCH(kern, grid, blk, lds, s, reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(out), L,
                   heads, QG, causal, obj, n_items);
     } else {

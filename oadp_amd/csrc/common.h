@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace oake {
 
@@ -17,6 +18,41 @@ extern thread_local hipEvent_t g_launch_start, g_launch_stop;
   hipExtLaunchKernelGGL(kern, grid, block, lds, stream, oake::g_launch_start, oake::g_launch_stop, 0, \
                         __VA_ARGS__)
 
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device and
+// handles may be driven from several host threads, so the "done" flag is an atomic bit per device (setting it
+// twice is harmless; devices beyond 63 set it on every launch).
+struct DynLdsAttr {
+  std::atomic<uint64_t> done{0};
+  hipError_t ensure(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = (dev >= 0 && dev < 64) ? 1ull << dev : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
+
+// compute units of the current device (cached per device; persistent kernels launch one block per CU)
+inline hipError_t device_cu_count(int* cus) {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) { *cus = c; return hipSuccess; }
+  }
+  int n = 0;
+  e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64) cache[dev].store(n, std::memory_order_relaxed);
+  *cus = n;
+  return hipSuccess;
+}
 
 typedef _Float16 f16_t;
 typedef __bf16 bf16_t;

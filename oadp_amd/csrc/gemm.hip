@@ -1519,14 +1519,9 @@ TileMap make_tilemap(const GemmArgs& a, int BM, int BN) {
 template <typename T, int EPI, int BM, int BN, int WM, int WN>
 hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * kRowBytes;
-  static bool attr_set = false;
+  static DynLdsAttr attr;
   auto kern = gemm_kernel<T, EPI, BM, BN, WM, WN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   const TileMap tmap = make_tilemap(a, BM, BN);
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
@@ -1541,14 +1536,9 @@ hipError_t launch_simple(const GemmArgs& a, hipStream_t s) {
 template <typename T, int EPI, int BM, int BN, int WM, int WN>
 hipError_t launch_deep(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 4 * (BM + BN) * kRowBytes;
-  static bool attr_set = false;
+  static DynLdsAttr attr;
   auto kern = gemm_deep_kernel<T, EPI, BM, BN, WM, WN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   const TileMap tmap = make_tilemap(a, BM, BN);
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
                reinterpret_cast<const float2*>(a.rowstat), a.colsum,
@@ -1562,14 +1552,9 @@ hipError_t launch_deep(const GemmArgs& a, hipStream_t s) {
 template <typename T, int EPI, int BM, int BN>
 hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
-  static bool attr_set = false;
+  static DynLdsAttr attr;
   auto kern = gemm_q4_kernel<T, EPI, BM, BN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   if (a.K < 2 * BK) return launch_simple<T, EPI, 128, 128, 2, 2>(a, s);
   const TileMap tmap = make_tilemap(a, BM, BN);
   EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
@@ -1585,20 +1570,11 @@ template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
   static_assert(BM <= 160 && BN <= 256, "EpiLds layout");
-  static bool attr_set = false;
-  static int num_cu = 0;
+  static DynLdsAttr attr;
   auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN, PH2>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-    num_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+  int num_cu = 0;
+  if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
   if (a.K < 3 * BK) {  // the EpiLds staging needs >= 3 K-tiles per tile
     if (a.patch_S != 0) return hipErrorInvalidValue;
     return launch_simple<T, EPI, BM, BN, WM, WN>(a, s);
@@ -1627,20 +1603,11 @@ template <typename T, int EPI, int BM, int BN>
 hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * kRowBytes + EpiLds::kBytes;
   static_assert(BM <= 160 && BN <= 256 && 2 * lds <= 160 * 1024, "two workgroups per CU");
-  static bool attr_set = false;
-  static int num_cu = 0;
+  static DynLdsAttr attr;
   auto kern = gemm_duo_kernel<T, EPI, BM, BN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-    num_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+  int num_cu = 0;
+  if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
   if (a.K < 3 * BK) {  // (as launch_pp: the callers' row-statistics hand-off assumes the same threshold)
     if (a.patch_S != 0) return hipErrorInvalidValue;
     return launch_simple<T, EPI, BM, BN, 2, 2>(a, s);
@@ -1773,12 +1740,8 @@ bool gemm_patch_padded_ok(int patch, int stride, int M, int N, int K, const Laun
 }
 
 hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s) {
-  int dev = 0;
-  hipDeviceProp_t prop;
-  hipError_t e = hipGetDevice(&dev);
-  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-  if (e != hipSuccess) return e;
-  const int cus = prop.multiProcessorCount;
+  int cus = 0;
+  if (hipError_t e = device_cu_count(&cus); e != hipSuccess) return e;
   OAKE_LAUNCH(mfma_probe_kernel, dim3(cus), dim3(512), 0, s, reinterpret_cast<const f16x8*>(d_frags), d_sink,
               iters);
   if (flop != nullptr) *flop = (double)cus * 8 * 20 * 16384.0 * (double)iters;

@@ -257,19 +257,26 @@ __global__ __launch_bounds__(256) void crop_normalize_jobs_kernel(const CropJob*
 
 }  // namespace
 
+// gridDim.y carries the job index and is limited to 65535: a flush's job list (all proposals / all block crops
+// of a whole batch of images) is launched in slices of at most kMaxJobsPerLaunch jobs.  Jobs are
+// self-describing (source image, scratch offsets, output row), so a slice is just a pointer offset.
+constexpr int kMaxJobsPerLaunch = 65535;
+
 hipError_t launch_crop_normalize_jobs(const CropJob* d_jobs, int njobs, int out_size, const float* mean3,
                                       const float* std3, void* out, int out_dtype, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
   if (out_size <= 0 || out_size % 8 != 0) return hipErrorInvalidValue;
-  const dim3 g((out_size * (out_size / 8) + 255) / 256, njobs), b(256);
-  if (out_dtype == DT_F32)
-    hipLaunchKernelGGL(crop_normalize_jobs_kernel<float>, g, b, 0, s, d_jobs, out_size, mean3[0], mean3[1],
-                       mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<float*>(out));
-  else if (out_dtype == DT_F16)
-    hipLaunchKernelGGL(crop_normalize_jobs_kernel<f16_t>, g, b, 0, s, d_jobs, out_size, mean3[0], mean3[1],
-                       mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<f16_t*>(out));
-  else
-    return hipErrorInvalidValue;
+  if (out_dtype != DT_F32 && out_dtype != DT_F16) return hipErrorInvalidValue;
+  for (int j0 = 0; j0 < njobs; j0 += kMaxJobsPerLaunch) {
+    const int nj = njobs - j0 < kMaxJobsPerLaunch ? njobs - j0 : kMaxJobsPerLaunch;
+    const dim3 g((out_size * (out_size / 8) + 255) / 256, nj), b(256);
+    if (out_dtype == DT_F32)
+      hipLaunchKernelGGL(crop_normalize_jobs_kernel<float>, g, b, 0, s, d_jobs + j0, out_size, mean3[0], mean3[1],
+                         mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<float*>(out));
+    else
+      hipLaunchKernelGGL(crop_normalize_jobs_kernel<f16_t>, g, b, 0, s, d_jobs + j0, out_size, mean3[0], mean3[1],
+                         mean3[2], std3[0], std3[1], std3[2], reinterpret_cast<f16_t*>(out));
+  }
   return hipGetLastError();
 }
 
@@ -277,26 +284,29 @@ hipError_t launch_resample(const ResampleJob* d_jobs, int njobs, int max_out, lo
                            int32_t* d_coef, int32_t* d_bounds, uint8_t* d_temp, int out_size,
                            const float* mean3, const float* std3, void* out, int out_dtype, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(resample_coeffs_kernel, dim3((max_out + 63) / 64, njobs, 2), dim3(64), 0, s,
-                     d_jobs, njobs, d_coef, d_bounds);
-  hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((max_ch_rw + 255) / 256), njobs), dim3(256), 0, s,
-                     d_jobs, d_coef, d_bounds, d_temp);
-  if (out_dtype == DT_U8) {  // whole-image resizes: every job writes its own image
-    hipLaunchKernelGGL(resample_v_u8_kernel, dim3((unsigned)((max_rh_rw + 255) / 256), njobs), dim3(256), 0,
-                       s, d_jobs, d_coef, d_bounds, d_temp);
-    return hipGetLastError();
+  if (out_dtype != DT_U8 && out_dtype != DT_F32 && out_dtype != DT_F16) return hipErrorInvalidValue;
+  for (int j0 = 0; j0 < njobs; j0 += kMaxJobsPerLaunch) {
+    const int nj = njobs - j0 < kMaxJobsPerLaunch ? njobs - j0 : kMaxJobsPerLaunch;
+    const ResampleJob* jobs = d_jobs + j0;
+    hipLaunchKernelGGL(resample_coeffs_kernel, dim3((max_out + 63) / 64, nj, 2), dim3(64), 0, s,
+                       jobs, nj, d_coef, d_bounds);
+    hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((max_ch_rw + 255) / 256), nj), dim3(256), 0, s,
+                       jobs, d_coef, d_bounds, d_temp);
+    if (out_dtype == DT_U8) {  // whole-image resizes: every job writes its own image
+      hipLaunchKernelGGL(resample_v_u8_kernel, dim3((unsigned)((max_rh_rw + 255) / 256), nj), dim3(256), 0,
+                         s, jobs, d_coef, d_bounds, d_temp);
+      continue;
+    }
+    const dim3 g((out_size * out_size + 255) / 256, nj), b(256);
+    if (out_dtype == DT_F32)
+      hipLaunchKernelGGL(resample_v_kernel<float>, g, b, 0, s, jobs, d_coef, d_bounds, d_temp,
+                         out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+                         reinterpret_cast<float*>(out));
+    else
+      hipLaunchKernelGGL(resample_v_kernel<f16_t>, g, b, 0, s, jobs, d_coef, d_bounds, d_temp,
+                         out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
+                         reinterpret_cast<f16_t*>(out));
   }
-  const dim3 g((out_size * out_size + 255) / 256, njobs), b(256);
-  if (out_dtype == DT_F32)
-    hipLaunchKernelGGL(resample_v_kernel<float>, g, b, 0, s, d_jobs, d_coef, d_bounds, d_temp,
-                       out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
-                       reinterpret_cast<float*>(out));
-  else if (out_dtype == DT_F16)
-    hipLaunchKernelGGL(resample_v_kernel<f16_t>, g, b, 0, s, d_jobs, d_coef, d_bounds, d_temp,
-                       out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2],
-                       reinterpret_cast<f16_t*>(out));
-  else
-    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -93,6 +93,9 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
         # True: workers only decode; crop / antialiased-bicubic resize / normalise run on the GPU
         # (csrc/resample.hip, bit-exact with the PIL path) — needs a HIP device in the main process
         self._device_preprocess = device_preprocess or bool(device_decode)
+        if self._device_preprocess:
+            from ..clip.preprocess import check_pillow_version
+            check_pillow_version()
         # True: the workers only read baseline JPEG files; they are decoded by the process that owns
         # the GPU (csrc/jpeg.hip: Huffman passes on native threads, the rest on the device,
         # bit-identical to PIL); files outside that subset (progressive, CMYK, PNG, ...) take the
@@ -334,6 +337,19 @@ def gather_counters(counters: Counters, device) -> list[list[float]]:
         torch.distributed.all_gather(out, t)
         return [o.tolist() for o in out]
     return [t.tolist()]
+
+
+def pick_backend(cuda: bool, gpus_here: int, env=None) -> str:
+    """Collective backend for the one counters gather.  RCCL ('nccl') needs a GPU per rank ON THIS NODE:
+    torchrun's LOCAL_WORLD_SIZE is the ranks per node (a multi-node run has more ranks in total than any node
+    has GPUs, and must still get RCCL); with more ranks than GPUs on a node — several processes per GPU: the host
+    side of the sweep (file reads, Huffman decode, .pth writing) scales with processes, DESIGN.md §5.5 — the
+    gather goes over gloo.  OAKE_DIST_BACKEND overrides."""
+    env = os.environ if env is None else env
+    if env.get('OAKE_DIST_BACKEND'):
+        return env['OAKE_DIST_BACKEND']
+    per_node = int(env.get('LOCAL_WORLD_SIZE') or env.get('WORLD_SIZE') or 1)
+    return 'nccl' if cuda and per_node <= gpus_here else 'gloo'
 
 
 class BaseValidator(ABC, Generic[T]):
@@ -603,11 +619,7 @@ class BaseValidator(ABC, Generic[T]):
         if Store.CUDA:
             torch.cuda.set_device(get_local_rank() % torch.cuda.device_count())
         if distributed:
-            # RCCL needs one GPU per rank; with more ranks than GPUs (several processes per GPU: the host side
-            # of the sweep — file reads, Huffman decode, .pth writing — scales with processes)
-            # the one counters gather goes over gloo
-            backend = os.environ.get('OAKE_DIST_BACKEND') or (
-                'nccl' if Store.CUDA and get_world_size() <= torch.cuda.device_count() else 'gloo')
+            backend = pick_backend(Store.CUDA, torch.cuda.device_count() if Store.CUDA else 0)
             torch.distributed.init_process_group(backend=backend)
 
         # the unpinned behaviours of the un-vendored fork (oadp_amd/clip/settings.py), before the model exists

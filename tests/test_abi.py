@@ -8,11 +8,12 @@ import subprocess
 from oadp_amd import _lib
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
-HEADER = ROOT / 'include' / 'oake_hip.h'
+HEADER = ROOT / 'include' / 'oake_hip.h'              # the reference-facing ABI
+DEBUG_HEADER = ROOT / 'include' / 'oake_hip_debug.h'  # kernel-level test / measurement entry points
 
 
-def _declared():
-    text = HEADER.read_text()
+def _declared(header=HEADER):
+    text = header.read_text()
     return sorted(set(re.findall(r'OAKE_API[^;]*?\b(oake_[a-z0-9_]+)\s*\(', text)))
 
 
@@ -27,6 +28,13 @@ def test_header_symbols_exported_and_bound(lib):
     assert set(_lib.SIGNATURES) == set(names)
     for n in names:
         assert getattr(lib, n) is not None
+    # the public header carries no lab bench: every oake_debug_* lives in oake_hip_debug.h
+    assert not [n for n in names if n.startswith('oake_debug_')]
+    debug = _declared(DEBUG_HEADER)
+    assert debug and all(n.startswith('oake_debug_') for n in debug)
+    assert set(debug) <= exported, set(debug) - exported
+    assert set(_lib.DEBUG_SIGNATURES) == set(debug)
+    assert exported == set(names) | set(debug), exported ^ (set(names) | set(debug))
 
 
 def test_abi_version_and_default_config(lib):

@@ -370,3 +370,26 @@ def test_device_decode_switches_dataloader_workers_off(coco, tmp_path, capsys):
     dl = Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(tmp_path / 'p'),
                              transform=_synth.preprocess()), num_workers=1)
     assert globals_.Validator('g', _synth.OracleModel(), dataloader=dl, device='cpu')._dataloader.num_workers == 1
+
+
+def test_backend_choice_counts_ranks_per_node():
+    """16 ranks on two 8-GPU nodes are one rank per GPU -> RCCL, not gloo."""
+    from oadp_amd.oake.base import pick_backend
+    assert pick_backend(True, 8, dict(WORLD_SIZE='16', LOCAL_WORLD_SIZE='8')) == 'nccl'
+    assert pick_backend(True, 8, dict(WORLD_SIZE='8')) == 'nccl'
+    assert pick_backend(True, 1, dict(WORLD_SIZE='2', LOCAL_WORLD_SIZE='2')) == 'gloo'  # two ranks share a GPU
+    assert pick_backend(False, 0, dict(WORLD_SIZE='2')) == 'gloo'
+    assert pick_backend(True, 8, dict(WORLD_SIZE='8', OAKE_DIST_BACKEND='gloo')) == 'gloo'
+
+
+def test_pillow_release_guard_warns_once(recwarn):
+    """the device resampler is pinned bit-exactly against one Pillow release; another one is
+    announced, not silently assumed."""
+    import PIL
+    from oadp_amd.clip import preprocess as pp
+    assert pp.check_pillow_version('%d.%d.0' % pp.PILLOW_PINNED) is True
+    assert pp.check_pillow_version(PIL.__version__) is True  # this image: the pinned release
+    pp._pillow_warned = False
+    assert pp.check_pillow_version('9.5.0') is False and pp.check_pillow_version('9.5.0') is False
+    hits = [w for w in recwarn.list if 'pinned bit-exactly' in str(w.message)]
+    assert len(hits) == 1
