@@ -402,10 +402,19 @@ class BaseValidator(ABC, Generic[T]):
                 print(f'[{self.name}] device_decode: num_workers {config["num_workers"]} -> 0 '
                       f'(files are read by a prefetch thread of this process)', flush=True)
             config['num_workers'] = 0
-        world = get_world_size()
+        world, rank = get_world_size(), get_rank()
+        # OAKE_SHARD=r/W: the DistributedSampler shard r of W without a process group — array-job style
+        # launches (one independent process per GPU or per node, nothing to rendezvous: the path has no
+        # data-path collective), and measuring one rank's share of a W-rank sweep on a single GPU
+        if os.environ.get('OAKE_SHARD'):
+            if world > 1:
+                raise RuntimeError('OAKE_SHARD and a torch.distributed launch (WORLD_SIZE > 1) are exclusive')
+            rank, world = (int(v) for v in os.environ['OAKE_SHARD'].split('/'))
+            if not 0 <= rank < world:
+                raise ValueError(f'OAKE_SHARD={os.environ["OAKE_SHARD"]}: need 0 <= r < W')
         if world > 1:
             config['sampler'] = torch.utils.data.distributed.DistributedSampler(
-                config['dataset'], num_replicas=world, rank=get_rank(), shuffle=False)
+                config['dataset'], num_replicas=world, rank=rank, shuffle=False)
         return torch.utils.data.DataLoader(batch_size=None, **config)
 
     @classmethod

@@ -76,6 +76,11 @@ def test_blocks_validator_full_size(cuda, tmp_path, vit_b32, monkeypatch):
         for s in levels:
             idx = [i for i, sc in enumerate(scale_of) if sc == s]
             rows.update((idx[0], idx[-1], idx[len(idx) // 2]))
+        # ... and, deliberately, the crops at the seams of the encoder pass: both images are one
+        # flush of 272 crops = 13 600 token rows, so crop c sits at flush rows 50 c ..: crops 159 / 160 / 161
+        # straddle GEMM tile rows 49 / 50 (160-row tiles), crop 244 is the last of image 0 (its neighbour in the
+        # batch belongs to another file) and the second image's first / last crops are flush crops 245 / 271
+        rows.update(r for r in (159, 160, 161, g['n_blocks'] - 1) if r < g['n_blocks'])
         rows = sorted(rows)
         host = host_ds._preprocess(id_, pathlib.Path('x'), PIL.Image.open(pathlib.Path(coco['root']) / name).convert('RGB'))
         assert host.blocks.shape[0] == g['n_blocks']
@@ -127,7 +132,9 @@ def test_objects_validator_full_size(cuda, tmp_path, vit_b32, monkeypatch):
     assert np.allclose(got_exp, gold['expanded'], rtol=0, atol=1e-3)
     assert [crops_ref.pil_crop_box(b) for b in got_exp] == [crops_ref.pil_crop_box(b) for b in gold['expanded']]
     # embeddings of a row subset against the oracle (PIL crops, fp32 dual-stream encoder)
-    rows = [0, 1, 57, 149, 150, 298, 299]
+    # (rows chosen on the seams of the 512-crop mini-batch's tiling, VERDICT r02 P2: 159 / 160 / 161 — crop 160
+    # starts at token row 31 520 = 197 x 160, the first row of GEMM tile row 197 — beside first, last and middle)
+    rows = [0, 1, 57, 149, 150, 159, 160, 161, 298, 299]
     sd = dict(vit_b32)
     sd['visual.positional_embedding'] = vis.positional_embedding
     ref = l2_normalize(encode_objects_ref(sd, ViTConfig(stride=16, padding=15), host.objects[rows], host.masks[rows]))

@@ -136,6 +136,21 @@ def test_sampler_shards_like_distributed_sampler(coco, tmp_path, monkeypatch):
     assert seen[1] == sorted({ids[i % len(ids)] for i in range(1, 6, 2)})
 
 
+def test_oake_shard_env_is_the_sampler_shard_without_a_process_group(coco, tmp_path, monkeypatch):
+    """OAKE_SHARD=r/W: rank r's DistributedSampler shard with nothing to rendezvous (array-job launches;
+    tools/sweep_shard.py measures one rank's share of the 8-GPU sweep with it)."""
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    ids = coco['ids']
+    for r in (0, 2):
+        monkeypatch.setenv('OAKE_SHARD', f'{r}/3')
+        out = tmp_path / f's{r}'
+        globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, out), device='cpu').run()
+        assert sorted(int(p.stem) for p in out.iterdir()) == sorted({ids[i % len(ids)] for i in range(r, 6, 3)})
+    monkeypatch.setenv('OAKE_SHARD', '3/3')
+    with pytest.raises(ValueError):
+        globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, tmp_path / 'bad'), device='cpu').run()
+
+
 def test_two_rank_gloo_run(coco, tmp_path):
     """world_size 2 over gloo: disjoint files, all images covered, counters gathered to rank 0."""
     out = tmp_path / 'dist'
