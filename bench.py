@@ -384,9 +384,14 @@ def _kernel_profile(model, work, one_lane_ms: float | None) -> tuple[dict, dict,
     v.profile(False)
     per_step = sum(p['seen'] for p in full)
     stride = next(s for s in (7, 11, 13, 17, 19) if per_step % s)
+    import torch
     v.profile(stride)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(stride):
         work.step(model)
+    torch.cuda.synchronize()
+    stamped_wall_ms = (time.perf_counter() - t0) / stride * 1e3  # wall clock of the very steps that were stamped
     prof = [p for p in v.profile_read() if p['launches'] > 0]
     v.profile(False)
     for p in prof:  # ms of ONE step: average stamped duration x launches per step
@@ -413,7 +418,11 @@ def _kernel_profile(model, work, one_lane_ms: float | None) -> tuple[dict, dict,
                            'tflops': round(p['flops'] / (p['total_ms'] * 1e-3) / 1e12, 1) if p['flops'] else None}
                for p in sorted(prof, key=lambda p: -p['ms_per_step'])}
     timing = {'kernels_sum_ms_per_step': round(tot, 4),
+              'one_lane_ms_per_step_while_stamping': round(stamped_wall_ms, 4),
               'one_lane_ms_per_step': None if one_lane_ms is None else round(one_lane_ms, 4),
+              'note': ('a stamped interval ends with the completion signal of that launch (~0.3 us that an '
+                       'un-instrumented kernel overlaps with its successor): the sum is bounded by the wall clock of '
+                       'the stamped steps themselves, and within ~1 % of the un-instrumented one-lane step'),
               'all_launches_stamped_sum_ms_per_step': round(sum(p['total_ms'] for p in full), 4),
               'launches_per_step': per_step, 'stamp_stride': stride}
     return roofline, kernels, timing
@@ -453,7 +462,7 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
         # A/B switches (per model: oake_set_option on every lane's handle).  OAKE_CLS_LAST=0 runs the last
         # block for every token, as the reference does; OAKE_GEMM_VARIANT forces a GEMM tile configuration.
         for env, opt in (('OAKE_GEMM_VARIANT', 'gemm_variant'), ('OAKE_CLS_LAST', 'cls_last'),
-                         ('OAKE_ATTN_VARIANT', 'attention_variant')):
+                         ('OAKE_ATTN_VARIANT', 'attention_variant'), ('OAKE_PATCH_DIRECT', 'patch_direct')):
             if env in os.environ:
                 model.visual.set_option(opt, int(os.environ[env]))
         work.build(model)
@@ -466,6 +475,16 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
     # (OAKE_BENCH_LANES=1: one stream, every kernel of a step strictly after the previous step's)
     n_lanes = args.lanes
     lane_streams = [torch.cuda.Stream(dev) for _ in range(n_lanes)] if not DRY_PLUMBING else []
+    # OAKE_BENCH_CU_SPLIT=<scheme> (two lanes): each lane's stream is restricted to one half of the compute units
+    # (hipExtStreamCreateWithCUMask; oadp_amd/cumask.py) and its handle sizes its persistent grids to that half:
+    # the two lanes' kernels then run side by side instead of taking turns on the whole chip
+    cu_split = os.environ.get('OAKE_BENCH_CU_SPLIT', '')
+    if cu_split and n_lanes == 2 and not DRY_PLUMBING:
+        from oadp_amd import cumask
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        lane_streams = [torch.cuda.ExternalStream(cumask.create_masked_stream(w), device=dev)
+                        for w in cumask.half_masks(ncu, cu_split)]
+        model.visual.set_option('cu_count', ncu // 2)
     step_no = [0]
 
     def step():
@@ -583,7 +602,8 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
                        'crops_per_step_per_gpu': work.crops,
                        'sharding': f'images x{world} (no data-path collective; ranks gathered: {ranks_seen})',
                        'launcher': 'torch.distributed.run, one process per GPU' if dist else 'single process',
-                       'backend': ctx['backend'] if dist else None, 'hip_streams': n_lanes},
+                       'backend': ctx['backend'] if dist else None, 'hip_streams': n_lanes,
+                       'cu_split': os.environ.get('OAKE_BENCH_CU_SPLIT') or None},
             'crops_per_sec': None if DRY_PLUMBING else round(crops_per_s, 1),
             # fraction of the 2.5 PFLOP/s data-sheet MFMA peak, end to end: on the FLOPs the library executes and
             # on the model's FLOPs per crop as SURVEY.md §8(d) defines them (the reference's execution)

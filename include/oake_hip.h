@@ -305,14 +305,20 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *   OAKE_OPT_ATTENTION_VARIANT  bit set of attention kernel forms (documented with
  *                               oake_debug_set_attention_variant, oake_hip_debug.h).  Default 31.
  *   OAKE_OPT_PATCH_DIRECT       conv1 gathers its patch rows straight from a 16-bit NCHW input batch (no
- *                               im2col pass) where the geometry allows it.  0 = always im2col.  Default 1.
+ *                               im2col pass) where the geometry allows it.  0 = always im2col.  2 = also from an
+ *                               FP32 batch (patch 32): the GEMM's DMA waves load, round and write the LDS image
+ *                               themselves (bit-identical; measured slower than im2col with two lanes).  Default 1.
+ *   OAKE_OPT_CU_COUNT           compute units the caller's stream may use: a handle driven on a CU-masked stream
+ *                               (hipExtStreamCreateWithCUMask: two lanes on disjoint halves of the chip) sizes the
+ *                               grids of its persistent kernels to that.  0 = every CU of the device.  Default 0.
  */
 enum {
   OAKE_OPT_CLS_LAST = 1,
   OAKE_OPT_GEMM_VARIANT = 2,
   OAKE_OPT_GEMM_PANEL = 3,
   OAKE_OPT_ATTENTION_VARIANT = 4,
-  OAKE_OPT_PATCH_DIRECT = 5
+  OAKE_OPT_PATCH_DIRECT = 5,
+  OAKE_OPT_CU_COUNT = 6
 };
 OAKE_API int oake_set_option(oake_handle* h, int option, int value);
 OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);

@@ -43,6 +43,10 @@ OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, 
                          int dtype16, void* stream);
 /* Raw ds_read_b64_tr_b16 semantics probe: in = 256 uint16, out = 64 lanes x 4 uint16. */
 OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
+/* Which compute units do a stream's blocks land on (CU-masked streams)?  nblocks blocks of one wave, one per CU
+ * (96 KiB of LDS each), each holding its CU for hold_us microseconds; d_out[2 b] = XCC id, d_out[2 b + 1] = the
+ * HW_ID register (CU / SH / SE fields) of block b. */
+OAKE_API int oake_debug_cu_census(uint32_t* d_out, int nblocks, int hold_us, void* stream);
 /* Measurement: a register-only MFMA stream (two waves per SIMD on every CU, `iters` x 20
  * v_mfma_f32_16x16x32_f16 per wave, no LDS or memory traffic) on the 9 x 64 x 8 f16 operand fragments at
  * d_frags16; *flop (host, may be NULL) receives the FLOPs of the launch.  Timed by the caller, it gives the

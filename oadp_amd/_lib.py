@@ -11,6 +11,7 @@ OAKE_ERR_INVALID, OAKE_ERR_HIP, OAKE_ERR_STATE, OAKE_ERR_UNKNOWN_TENSOR, OAKE_ER
 OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
 OAKE_OPT_CLS_LAST, OAKE_OPT_GEMM_VARIANT, OAKE_OPT_GEMM_PANEL, OAKE_OPT_ATTENTION_VARIANT = 1, 2, 3, 4
 OAKE_OPT_PATCH_DIRECT = 5
+OAKE_OPT_CU_COUNT = 6
 ABI_VERSION = 3
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library
@@ -77,6 +78,7 @@ DEBUG_SIGNATURES = {
     'oake_debug_layernorm': (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),
     'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
+    'oake_debug_cu_census': (_I, [_VP, _I, _I, _VP]),
     'oake_debug_mfma_probe': (_I, [_VP, _VP, C.c_int, C.POINTER(C.c_double), _VP]),
     'oake_debug_set_attention_variant': (_I, [_I]),
     'oake_debug_set_gemm_variant': (_I, [_I]),
@@ -107,6 +109,8 @@ def load() -> C.CDLL:
             '(or __graft_entry__.build()); there is no CPU fallback')
     lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_LOCAL)
     for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
+        if name in DEBUG_SIGNATURES and os.environ.get('OAKE_LIB') and not hasattr(lib, name):
+            continue  # an older experiment build (tools/ab_env.py) may lack a newer debug entry point
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args

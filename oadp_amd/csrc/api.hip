@@ -718,9 +718,18 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
                       gemm_patch_padded_ok(c.patch_size, c.stride, a.M, a.N, a.K, &h->opts) &&
                       (h->grid - 1) * c.stride + c.patch_size <= hp &&
                       (size_t)3 * hp * ws <= (size_t)h->p2 * h->kpatch;  // fits the im2col buffer
-  if (direct) {
+  // fp32 images in the plain geometry (what the reference hands over, globals.py:54-57): the same gather, with
+  // the cast done by the GEMM's DMA waves on the way into LDS — no im2col pass either.  Opt-in (patch_direct = 2):
+  // measured, the register-staged A path makes conv1 97.8 us against 60.5 + 43.2 for GEMM + im2col — +0.3 % on one
+  // lane, but -0.6 % with two lanes (the DMA waves' ordinary loads and ds_writes cost the partner lane more than
+  // the im2col pass did), profiles/r03/ab_session_e_*.log
+  const bool direct32 = !direct && h->patch_direct >= 2 && in_dtype == DT_F32 && h->xdt != DT_F32 &&
+                        gemm_patch_f32_ok(c.image_size, c.patch_size, c.stride, c.padding, a.M, a.N, a.K, &h->opts) &&
+                        reinterpret_cast<uintptr_t>(imgs) % 16 == 0;
+  if (direct || direct32) {
     a.A = imgs;
     a.patch_S = c.image_size; a.patch_P = c.patch_size; a.patch_G = h->grid;
+    a.patch_f32 = direct32 ? 1 : 0;
   } else if (padded) {
     RUN(h, s, "pad_nchw", 0.0, (double)nb * 3 * hp * ws * 2 + (double)nb * 3 * c.image_size * c.image_size * in_es,
         launch_pad_nchw(h->dt16, imgs, in_dtype, h->a_patch, nb, c.image_size, c.padding, hp, ws, s));
@@ -1662,6 +1671,11 @@ int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
   return dbg(launch_tr_read_probe(d_in, d_out, reinterpret_cast<hipStream_t>(stream)));
 }
 
+int oake_debug_cu_census(uint32_t* d_out, int nblocks, int hold_us, void* stream) {
+  if (!d_out || nblocks < 1 || hold_us < 0) return OAKE_ERR_INVALID;
+  return dbg(launch_cu_census(d_out, nblocks, hold_us, reinterpret_cast<hipStream_t>(stream)));
+}
+
 int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream) {
   if (d_frags16 == nullptr || d_sink == nullptr || iters < 1) return OAKE_ERR_INVALID;
   return dbg(launch_mfma_probe(d_frags16, d_sink, iters, flop, reinterpret_cast<hipStream_t>(stream)));
@@ -1703,7 +1717,8 @@ int oake_set_option(oake_handle* h, int option, int value) {
     case OAKE_OPT_GEMM_VARIANT: h->opts.gemm_variant = value < 0 ? -1 : value; return OAKE_OK;
     case OAKE_OPT_GEMM_PANEL: h->opts.gemm_panel = value; return OAKE_OK;
     case OAKE_OPT_ATTENTION_VARIANT: h->opts.attention_variant = value & 127; return OAKE_OK;
-    case OAKE_OPT_PATCH_DIRECT: h->patch_direct = value ? 1 : 0; return OAKE_OK;
+    case OAKE_OPT_PATCH_DIRECT: h->patch_direct = value < 0 ? 0 : (value > 2 ? 2 : value); return OAKE_OK;
+    case OAKE_OPT_CU_COUNT: h->opts.cu_count = value > 0 ? value : 0; return OAKE_OK;
     default: return fail(h, OAKE_ERR_INVALID, "unknown option " + std::to_string(option));
   }
 }
@@ -1716,6 +1731,7 @@ int oake_get_option(const oake_handle* h, int option, int* value) {
     case OAKE_OPT_GEMM_PANEL: *value = h->opts.gemm_panel; return OAKE_OK;
     case OAKE_OPT_ATTENTION_VARIANT: *value = h->opts.attention_variant; return OAKE_OK;
     case OAKE_OPT_PATCH_DIRECT: *value = h->patch_direct; return OAKE_OK;
+    case OAKE_OPT_CU_COUNT: *value = h->opts.cu_count; return OAKE_OK;
     default: return OAKE_ERR_INVALID;
   }
 }

@@ -420,7 +420,7 @@ void attention_pair_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L
   for (int i = 0; i < 4; ++i) {
     const int row = q0 + (lane >> 3) + 8 * i;
     const uint4 v = *reinterpret_cast<const uint4*>(ks + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
-    if (valid && row < L) *reinterpret_cast<uint4*>(obase + (size_t)row * C + (lane & 7) * 8) = v;
+    if (valid && row < L) aux_store16(obase + (size_t)row * C + (lane & 7) * 8, v);
   }
 }
 
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   for (int i = 0; i < 2 * MT; ++i) {
     const int row = (lane >> 3) + 8 * i;
     const uint4 v = *reinterpret_cast<const uint4*>(stage + row * kVStride + (lane & 7) * 8);
-    if (q0 + row < L) *reinterpret_cast<uint4*>(obase + (size_t)(q0 + row) * C + (lane & 7) * 8) = v;
+    if (q0 + row < L) aux_store16(obase + (size_t)(q0 + row) * C + (lane & 7) * 8, v);
   }
 }
 
@@ -1351,6 +1351,28 @@ hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* q
   if (dtype16 == DT_F16) return obj_attn_t<f16_t>(qkv_x, qkv_y, mask, mask_dtype, out, n, L, heads, s);
   if (dtype16 == DT_BF16) return obj_attn_t<bf16_t>(qkv_x, qkv_y, mask, mask_dtype, out, n, L, heads, s);
   return hipErrorInvalidValue;
+}
+
+__global__ __launch_bounds__(64) void cu_census_kernel(unsigned* __restrict__ out, int hold_ticks) {
+  extern __shared__ char census_lds[];
+  unsigned xcc, hwid;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < (unsigned long long)hold_ticks) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    census_lds[0] = 1;  // (the LDS allocation is what keeps blocks one per CU)
+    out[2 * blockIdx.x] = xcc;
+    out[2 * blockIdx.x + 1] = hwid;
+  }
+}
+
+hipError_t launch_cu_census(unsigned* out, int nblocks, int hold_us, hipStream_t s) {
+  static DynLdsAttr attr;
+  constexpr int lds = 96 * 1024;  // more than half a CU's LDS: one block per CU
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(cu_census_kernel), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(cu_census_kernel, dim3(nblocks), dim3(64), lds, s, out, hold_us * 100);  // wall clock: 100 MHz
+  return hipGetLastError();
 }
 
 hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s) {

@@ -168,6 +168,34 @@ __device__ __forceinline__ V swap_piece(V mine, V theirs, bool take_in_upper_row
   return out;
 }
 
+// 16-byte global stores with an explicit cache policy (gemm.hip documents why: a kernel's output is read by the
+// NEXT kernel from any XCD, so it must reach the fabric anyway — written through (sc1) it leaves while the kernel is
+// still computing instead of at its end-of-kernel release).  POLICY 0 = plain, 1 = sc1 (write-through, line dropped
+// from the XCD's L2), 2 = nt, 3 = sc0 sc1.  Inline asm (no builtin carries the cache bits of a flat global store);
+// the trailing s_nop keeps hipcc from overwriting the data registers before the store has read them, the "memory"
+// clobber keeps later loads of the same location behind the store in program order.
+template <int POLICY, typename P>
+__device__ __forceinline__ void store16_policy(P* p, u32x4_t v) {
+  if constexpr (POLICY == 1)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if constexpr (POLICY == 2)
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if constexpr (POLICY == 3)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else
+    *reinterpret_cast<u32x4_t*>(p) = v;
+}
+__device__ __forceinline__ u32x4_t as_u32x4(uint4 v) { return u32x4_t{v.x, v.y, v.z, v.w}; }
+// the kernels beside the GEMMs whose output is a whole activation / operand buffer (attention output, im2col
+// matrix): same reasoning, separate switch for A/B builds (-DOAKE_AUX_STORE_POLICY=n)
+#ifndef OAKE_AUX_STORE_POLICY
+#define OAKE_AUX_STORE_POLICY 1
+#endif
+template <typename P>
+__device__ __forceinline__ void aux_store16(P* p, uint4 v) {
+  store16_policy<OAKE_AUX_STORE_POLICY>(p, as_u32x4(v));
+}
+
 // QuickGELU (OpenAI CLIP): x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)).
 // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division: the result is rounded to 16 bits
 // right after, and the c_fc epilogue evaluates this 80 times per lane per tile.

@@ -54,6 +54,10 @@ struct EpiParams {
   // the residual epilogue (EPI_RESID16) leaves (sum x, sum x^2) of every 64-column slice of a row in
   // rowpart_out[m][kRowParts] (slice = column / 64); the next LN-folded GEMM's DMA waves add up the
   // first `nparts` slices of its rows (fixed order) and put (rstd, -mean rstd) into LDS.
+  // (Round 3 measured the slice-major layout [slice][m] — an MFMA row tile's 16 rows as ONE 128-byte line per wave
+  // instead of 16 lines of 8 bytes, coalesced 8-byte loads on the consumer side: -1.0 % on the bench, five
+  // interleaved rounds, profiles/r03/ab_rowpart_xl_a32.log.  The row-major form keeps a row's 12 slices in one
+  // line, which the consumer fetches with six 16-byte loads per lane; it stays.)
   float2* rowpart_out;
   const float2* rowpart_in;
   int nparts;
@@ -68,6 +72,38 @@ struct TileMap {
   int by_m;  // 0: panels of pn tile-columns, row-major inside;  1: slabs of pn tile-rows, column-major inside
   unsigned long long* trace;  // [block < 64][group 2][tile < 8][4] cycle stamps, or nullptr
 };
+
+// Cache policy of the 16-byte tile stores.  1 (production) = sc1: write-through, the line is not kept in the XCD's
+// L2.  A GEMM's output is read by the NEXT kernel, from any XCD, so it has to reach the fabric anyway; with plain
+// (write-back) stores it does so at the kernel's end-of-kernel release — up to 20 MB of dirty lines that every CU
+// waits for with nothing left to compute (ours 'bias' - 'none' epilogue = 4.4-5.2 us for 19.7 MB on the
+// one-tile-per-CU shapes) — with write-through stores it leaves under the K loops that are still running.
+// Measured (tools/ab_env.py, one session, four interleaved rounds, profiles/r03/ab_session_f_store_policy.log):
+// plain 107.1 k images/s, sc1 109.2 k (+2.0 %; one lane +2.6 %), sc0 sc1 109.2 k, nt 106.8 k.
+// Measurement builds of the other policies: OAKE_EXTRA_FLAGS=-DOAKE_STORE_POLICY=n with OAKE_LIB_OUT
+// (0 = plain, 2 = nt, 3 = sc0 sc1).  The stores are inline asm (no builtin carries the cache bits for a flat
+// global store): they end with the s_nop that keeps hipcc from overwriting the data registers early, and the
+// "memory" clobber keeps the residual epilogue's loads of x behind them in program order.
+#ifndef OAKE_STORE_POLICY
+#define OAKE_STORE_POLICY 1
+#endif
+// ... for the stores that write FULL 128-byte lines (the lane-swapped tile stores of interior tiles: c_fc, out_proj,
+// c_proj).  The epilogues that store in accumulator layout — 16 rows x 64 bytes per instruction: the trickled
+// pieces of qkv, conv1's token-remapped rows, edge tiles — keep plain stores: the two half lines of a row are
+// written by different instructions (or K-tiles apart) and only a write-back L2 merges them into one line
+// (written through, they were -1.9 % in objects mode, where a kernel has 15 tiles per CU and its end-of-kernel
+// release hardly matters: profiles/r03/ab_session_g_store_policy_objects.log).
+#ifndef OAKE_STORE_POLICY_PARTIAL
+#define OAKE_STORE_POLICY_PARTIAL 0
+#endif
+template <typename P>
+__device__ __forceinline__ void tile_store16(P* p, u32x4_t v) {  // full-line instruction
+  store16_policy<OAKE_STORE_POLICY>(p, v);
+}
+template <typename P>
+__device__ __forceinline__ void tile_store16_partial(P* p, u32x4_t v) {  // half lines per instruction
+  store16_policy<OAKE_STORE_POLICY_PARTIAL>(p, v);
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -332,12 +368,12 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
         if constexpr (SWAP)
           qv[t] = u32x4_t{q0.x, q0.y, q1.x, q1.y};
         else
-          *reinterpret_cast<uint4*>(orow_ptr + n) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+          tile_store16_partial(orow_ptr + n, u32x4_t{q0.x, q0.y, q1.x, q1.y});
       }
       if constexpr (SWAP) {
         T* pa = orow_ptr + (ptrdiff_t)swap_row * ep.ldo + nwave + 8 * g + swap_col;
-        *reinterpret_cast<u32x4_t*>(pa) = swap_piece(qv[0], qv[1], true);
-        *reinterpret_cast<u32x4_t*>(pa + (size_t)8 * ep.ldo) = swap_piece(qv[1], qv[0], false);
+        tile_store16(pa, swap_piece(qv[0], qv[1], true));
+        tile_store16(pa + (size_t)8 * ep.ldo, swap_piece(qv[1], qv[0], false));
       }
       if constexpr (EPI == EPI_RESID16) {
         if (mi + kAhead < MI) OAKE_FETCH_RESID(mi + kAhead < MI ? mi + kAhead : 0);
@@ -453,7 +489,7 @@ __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&p
       const uint2 p1 = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
       const uint4 pk = make_uint4(p0.x, p0.y, p1.x, p1.y);
       if (mi < MI0)  // the 168-VGPR budget (3 waves per SIMD) holds MI - MI0 rows; the rest go now
-        *reinterpret_cast<uint4*>(row0_ptr + (size_t)mi * 16 * ep.ldo + t * 32) = pk;
+        tile_store16_partial(row0_ptr + (size_t)mi * 16 * ep.ldo + t * 32, as_u32x4(pk));
       else
         pend[mi - MI0][t] = pk;
     }
@@ -847,7 +883,7 @@ __global__ __launch_bounds__(512) void gemm_q4_kernel(const T* __restrict__ A, c
 //     straight across tile boundaries, so there is no per-tile prologue and the epilogue's stores
 //     drain under the next tile's MFMAs.
 // Measured: 1520 cycles per K-tile in the loop = 84 % MFMA utilisation.
-template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false>
+template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false, bool A32 = false>
 __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __restrict__ A,
                                                                      const T* __restrict__ W, int M,
                                                                      int N, int K, EpiParams ep,
@@ -885,7 +921,6 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   if (my_tiles == 0) return;
   const int nk = K / BK;
   const int total = my_tiles * nk;  // flat K-tile count of this block
-
 #define OAKE_PIN() __builtin_amdgcn_sched_barrier(0)
 #define OAKE_BAR()                   \
   do {                               \
@@ -903,12 +938,82 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       tile_origin(tmap, xb + xslot + tile_i * per_xcd, BM, BN, m0, n0);
 #pragma unroll
       for (int j = 0; j < NPL; ++j)
-        src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane, ep.patch_S,
-                                              ep.patch_P, ep.patch_G, ep.patch_T, ep.patch_H);
+        if (!A32 || j >= BM / 8 / NL)  // (A32: the A rows go through registers, a32_set_src)
+          src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane, ep.patch_S,
+                                                ep.patch_P, ep.patch_G, ep.patch_T, ep.patch_H);
     };
     // pieces lw + NL j with j < kAPieces are A rows for every DMA wave (BM / 8 is a multiple of NL)
     static_assert((BM / 8) % NL == 0, "A pieces split evenly over the DMA waves");
     constexpr int kAPieces = BM / 8 / NL;
+    // A32 (conv1 on an fp32 NCHW batch, patch 32): the A half of a stage does not come by LDS-DMA (a raw copy) but
+    // through this wave's registers.  A K-tile is two pixel rows ("runs") of 32 floats = one 128-byte line each per
+    // tile row; piece j = 8 tile rows, lane (row = lane >> 3, c = lane & 7) fetches floats [4c, 4c+4) of run 0 and of
+    // run 1 — two instructions of 8 FULL lines each (fetching 8 consecutive floats per lane instead touches 16 half
+    // lines per instruction, which the vector memory path serves at half the rate).  Adjacent lanes then swap one
+    // float4 (quad_perm DPP): the even lane ends up with 8 consecutive floats of run 0, the odd lane with 8 of run
+    // 1, i.e. one 16-byte chunk of the 16-bit LDS image each; rounded to T (RNE, as im2col's cast) and written with
+    // ds_write_b128 into the same swizzled image the LDS-DMA would have produced.  The rows of flat K-tile g+2 are
+    // requested in iteration g and written at the top of iteration g+1 (one register set; a second set for two
+    // K-tiles of look-ahead does not fit the 168-register budget: 152 bytes of scratch).
+    static_assert(!A32 || (PH2 && EPI == EPI_PATCH16 && sizeof(T) == 2), "A32: conv1 on the long-phase kernel");
+    const float* asrc[A32 ? kAPieces : 1];  // lane's float4 of run 0 of piece j at K-tile 0
+    int adst[A32 ? kAPieces : 1];           // byte offset of the lane's 16-byte chunk inside a stage
+    float4 areg[A32 ? 2 * kAPieces : 1];
+    int a_buf = 0;                          // ring slot the next write fills
+    auto a32_set_src = [&](int tile_i) {
+      if constexpr (A32) {
+        int m0, n0;
+        tile_origin(tmap, xb + xslot + tile_i * per_xcd, BM, BN, m0, n0);
+        const float* A32p = reinterpret_cast<const float*>(A);
+        const int pS = ep.patch_S, pP = ep.patch_P, pG = ep.patch_G;
+#pragma unroll
+        for (int j = 0; j < kAPieces; ++j) {
+          const int rr = 8 * (lw + NL * j) + (lane >> 3), c = lane & 7;
+          int gr = m0 + rr;
+          gr = gr < M ? gr : M - 1;
+          const int img = gr / (pG * pG), p = gr - img * pG * pG;
+          const int py = p / pG, px = p - py * pG;
+          asrc[j] = A32p + (size_t)img * 3 * pS * pS + (size_t)(py * pP) * pS + px * pP + 4 * c;
+          const int cc = (c & 1) * 4 + (c >> 1);  // the K-tile's 16-byte chunk this lane assembles
+          adst[j] = rr * kRowBytes + ((cc ^ ((rr >> 1) & 7)) << 4);
+        }
+      }
+    };
+    auto a32_load = [&](int kt) {  // K-tile kt: channel kt / 16, pixel rows 2 (kt % 16), 2 (kt % 16) + 1 of the patch
+      if constexpr (A32) {
+        const int k0 = kt * BK, pp = ep.patch_P * ep.patch_P;
+        const int ch = k0 / pp, ky0 = (k0 - ch * pp) / ep.patch_P;
+        const size_t off = ((size_t)ch * ep.patch_S + ky0) * ep.patch_S;
+#pragma unroll
+        for (int j = 0; j < kAPieces; ++j) {
+          areg[2 * j] = *reinterpret_cast<const float4*>(asrc[j] + off);
+          areg[2 * j + 1] = *reinterpret_cast<const float4*>(asrc[j] + off + ep.patch_S);
+        }
+      }
+    };
+    auto a32_write = [&]() {
+      if constexpr (A32) {
+        typedef typename T16<T>::vec8 vec8w;
+        char* base = smem + a_buf * kStageBytes;
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int j = 0; j < kAPieces; ++j) {
+          const float4 r0 = areg[2 * j], r1 = areg[2 * j + 1];
+          const float4 send = odd ? r0 : r1;  // what the neighbour needs
+          float4 recv;
+          recv.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.x), 0xB1, 0xF, 0xF, true));
+          recv.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.y), 0xB1, 0xF, 0xF, true));
+          recv.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.z), 0xB1, 0xF, 0xF, true));
+          recv.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send.w), 0xB1, 0xF, 0xF, true));
+          const float4 lo = odd ? recv : r0, hi = odd ? r1 : recv;
+          vec8w v;
+          v[0] = to16<T>(lo.x); v[1] = to16<T>(lo.y); v[2] = to16<T>(lo.z); v[3] = to16<T>(lo.w);
+          v[4] = to16<T>(hi.x); v[5] = to16<T>(hi.y); v[6] = to16<T>(hi.z); v[7] = to16<T>(hi.w);
+          *reinterpret_cast<vec8w*>(base + adst[j]) = v;
+        }
+        a_buf = a_buf == NSTAGE - 1 ? 0 : a_buf + 1;
+      }
+    };
     // producer cursor: flat K-tile s_g (k position s_kt of tile s_tile) goes to ring slot s_buf
     int s_g = 0, s_kt = 0, s_tile = 0, s_buf = 0;
     // consumer position (compute group 0): K-tile d_kt of tile d_tile.  In the last phase of a tile's
@@ -946,8 +1051,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       const size_t _koff = (size_t)s_kt * (BK * 2);                                          \
       const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P, ep.patch_H) : _koff; \
       _Pragma("unroll") for (int _j = (j0_); _j < (j1_); ++_j)                               \
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
-                                           (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0); \
+          if (!A32 || _j >= kAPieces)                                                        \
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
+                                             (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0); \
     }                                                                                        \
   } while (0)
 #define OAKE_ADVANCE()                                    \
@@ -958,19 +1064,30 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       if (++s_kt == nk) {                                 \
         s_kt = 0;                                         \
         ++s_tile;                                         \
-        if (s_tile < my_tiles) set_src(s_tile);           \
+        if (s_tile < my_tiles) {                          \
+          set_src(s_tile);                                \
+          a32_set_src(s_tile);                            \
+        }                                                 \
       }                                                   \
     }                                                     \
   } while (0)
     // vmcnt immediate: bits [3:0] | [15:14]; expcnt 7 and lgkmcnt 15 = "don't wait"
 #define OAKE_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
     constexpr int Q1 = (NPL + 3) / 4, Q2 = (2 * NPL + 3) / 4, Q3 = (3 * NPL + 3) / 4;
+    // vmcnt entries one K-tile's worth of this wave's requests occupies
+    constexpr int kPerKt = A32 ? (NPL - kAPieces) + 2 * kAPieces : NPL;
+    static_assert(kPerKt <= 63, "vmcnt immediate");
     set_src(0);
+    a32_set_src(0);
+    if constexpr (A32) a32_load(0);  // A rows of flat K-tile 0 ...
+    OAKE_STAGE(0, NPL);
+    if constexpr (A32) a32_write();  // ... into slot 0 (hipcc waits for the loads here)
+    OAKE_ADVANCE();
+    if constexpr (A32) a32_load(s_kt);  // flat K-tile 1: stays in registers until iteration 0 writes it
     OAKE_STAGE(0, NPL);
     OAKE_ADVANCE();
-    OAKE_STAGE(0, NPL);
-    OAKE_ADVANCE();
-    if (total >= 2) OAKE_VMCNT(NPL); else OAKE_VMCNT(0);
+    if (total >= 2) OAKE_VMCNT(kPerKt); else OAKE_VMCNT(0);
+    if constexpr (A32) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's A rows of K-tile 0 are in LDS
     OAKE_BAR();  // b0: flat K-tile 0 published
     // LN-folded epilogues: DMA wave lw owns rows [lw * BM/4, +BM/4) of the tile, one row per lane.  At
     // the tile's first K-tile it loads the row's partial (sum x, sum x^2) slices, adds them up in
@@ -1012,6 +1129,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
           st_shift = -_mean * st_rstd;
         }
       }
+      if constexpr (A32) {
+        // flat K-tile g+1's A rows (requested during iteration g-1) -> LDS; then request those of g+2 under this
+        // iteration.  (The cursor s_kt / asrc stands at flat K-tile g+2.)
+        if (g + 1 < total) a32_write();
+        if (s_g < total) a32_load(s_kt);
+      }
       if constexpr (PH2) {  // two long phases per K-tile: half of the pieces in each
         OAKE_STAGE(0, Q2);
         OAKE_BAR();
@@ -1042,9 +1165,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       OAKE_STAGE(Q3, NPL);
       }
       OAKE_STAGE_EPI();
+      // (with the residual tile staged behind the last K-tile, iteration total - 2 has issued a full set of
+      // NPL pieces too — part 0 — and must not wait for them to publish K-tile total - 1)
       const bool newer = g + 2 < total;
       OAKE_ADVANCE();
-      if (newer) OAKE_VMCNT(NPL); else OAKE_VMCNT(0);  // flat K-tile g+1 landed
+      if (newer) OAKE_VMCNT(kPerKt); else OAKE_VMCNT(0);  // flat K-tile g+1 landed
+      if constexpr (A32) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the A rows written at the top
       OAKE_BAR();  // publishes K-tile g+1; K-tile g's slot is free from here on
     }
     OAKE_BAR();  // pairs with compute group 1's last phase
@@ -1108,8 +1234,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   T* pend_ptr = nullptr;  // lane's address of the tile's first row-block (mi = 0, t = 0)
   int pend_next = NPEND;  // next pending piece to store (NPEND = none)
 #define OAKE_STORE_PEND(i_)                                                                  \
-  *reinterpret_cast<uint4*>(pend_ptr + (size_t)((i_) / (NI / 2) + MI0) * 16 * ep.ldo +       \
-                            ((i_) % (NI / 2)) * 32) = pend[(i_) / (NI / 2)][(i_) % (NI / 2)]
+  tile_store16_partial(pend_ptr + (size_t)((i_) / (NI / 2) + MI0) * 16 * ep.ldo + ((i_) % (NI / 2)) * 32, \
+               as_u32x4(pend[(i_) / (NI / 2)][(i_) % (NI / 2)]))
 
   const unsigned long long t_entry = trace ? __builtin_readcyclecounter() : 0;
   if (trace != nullptr && tid == 0) trace[4096 + blockIdx.x * 2] = wall_clock64();
@@ -1566,15 +1692,16 @@ hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false>
+template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false, bool A32 = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
   static_assert(BM <= 160 && BN <= 256, "EpiLds layout");
   static DynLdsAttr attr;
-  auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN, PH2>;
+  auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN, PH2, A32>;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   int num_cu = 0;
   if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
+  if (a.opts && a.opts->cu_count > 0 && a.opts->cu_count < num_cu) num_cu = a.opts->cu_count;  // CU-masked stream
   if (a.K < 3 * BK) {  // the EpiLds staging needs >= 3 K-tiles per tile
     if (a.patch_S != 0) return hipErrorInvalidValue;
     return launch_simple<T, EPI, BM, BN, WM, WN>(a, s);
@@ -1608,6 +1735,7 @@ hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   int num_cu = 0;
   if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
+  if (a.opts && a.opts->cu_count > 0 && a.opts->cu_count < num_cu) num_cu = a.opts->cu_count;  // CU-masked stream
   if (a.K < 3 * BK) {  // (as launch_pp: the callers' row-statistics hand-off assumes the same threshold)
     if (a.patch_S != 0) return hipErrorInvalidValue;
     return launch_simple<T, EPI, BM, BN, 2, 2>(a, s);
@@ -1654,6 +1782,9 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 2: return launch_simple<T, EPI, 320, 128, 4, 2>(a, s);
     case 3: return launch_simple<T, EPI, 256, 256, 2, 4>(a, s);
     case 4:  // production: two long phases per K-tile where the epilogue keeps no tile pending (residual, conv1)
+      if constexpr (EPI == EPI_PATCH16) {
+        if (a.patch_f32) return launch_pp<T, EPI, 160, 256, 2, 4, true, true>(a, s);
+      }
       if constexpr (EPI == EPI_RESID16 || EPI == EPI_PATCH16)
         return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
       // ... and for c_fc's epilogue (LayerNorm affine + QuickGELU): long phases + all stores at the tile end
@@ -1748,8 +1879,21 @@ hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, doub
   return hipGetLastError();
 }
 
+bool gemm_patch_f32_ok(int image, int patch, int stride, int padding, int M, int N, int K,
+                       const LaunchOpts* opts) {
+  // the 16-bit gather's geometry, on the production configuration of the persistent kernel (the one instantiated
+  // with the register-staged A path), 8 floats per lane = 32 contiguous bytes of a patch row
+  GemmArgs a{};
+  a.M = M; a.N = N; a.K = K; a.opts = opts;
+  const int v = pick_variant(a);
+  return gemm_patch_direct_ok(image, patch, stride, padding, M, N, K, opts) && v == 4 && patch == 32;
+}
+
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+  if (a.patch_f32 && (epi != EPI_PATCH16 || a.patch_S == 0 || a.patch_T != 0 || a.patch_P != 32 ||
+                      pick_variant(a) != 4))
+    return hipErrorInvalidValue;
   if (a.patch_S != 0 && !gemm_uses_persistent(a.M, a.N, a.K, a.opts)) return hipErrorInvalidValue;
   if (a.K % BK != 0 || a.N % 4 != 0 || a.ldo % 4 != 0) return hipErrorInvalidValue;
   if ((epi == EPI_T16_BIAS || epi == EPI_T16_GELU || epi == EPI_RESID16 || epi == EPI_PATCH16 ||

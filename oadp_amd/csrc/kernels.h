@@ -35,6 +35,8 @@ struct LaunchOpts {
   int gemm_panel = 0;      // tile order: 0 default, n > 0 N panels of n tiles, n < 0 M slabs of -n tiles
   unsigned long long* gemm_trace = nullptr;  // device buffer for per-tile cycle stamps, or nullptr
   int attention_variant = 31;                // bits: see oake_debug_set_attention_variant
+  int cu_count = 0;        // compute units the launch stream may use (0 = all of the device): a handle driven on a
+                           // CU-masked stream (hipExtStreamCreateWithCUMask) sizes its persistent grids to that
 };
 
 struct GemmArgs {
@@ -67,10 +69,17 @@ struct GemmArgs {
   // the general form: A = a zero-padded 16-bit buffer [n,3,patch_H,patch_S] (patch_S = row stride in pixels, a
   // multiple of 8), patch origins patch_T pixels apart (0: patch_T = patch_P, patch_H = patch_S, i.e. the above)
   int patch_T, patch_H;
+  // patch_S != 0 in the plain geometry (patch_T == 0) with an FP32 image batch: the DMA waves fetch the patch
+  // rows with ordinary 16-byte loads, round them to the 16-bit operand type and write the LDS image themselves
+  // (no im2col pass and no 16-bit copy of the batch; EPI_PATCH16 on the persistent kernel only)
+  int patch_f32;
 };
 // true when the conv1 GEMM can read its A operand straight from the NCHW batch (no im2col pass)
 bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,
                           const LaunchOpts* opts = nullptr);
+// ... and when that batch may be fp32 (cast on the way into LDS by the DMA waves)
+bool gemm_patch_f32_ok(int image, int patch, int stride, int padding, int M, int N, int K,
+                       const LaunchOpts* opts = nullptr);
 // ... or from a zero-padded copy of it (strides that cut patches, padding: objects mode)
 bool gemm_patch_padded_ok(int patch, int stride, int M, int N, int K, const LaunchOpts* opts = nullptr);
 
@@ -216,6 +225,9 @@ hipError_t launch_jpeg_reconstruct(const JpegFrame& frame, const int16_t* d_coef
                                    uint8_t* d_out_hwc, hipStream_t s);
 
 hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s);
+// one block per CU (large dynamic LDS), each records (XCC id, HW_ID) and holds its CU for ~hold_us: which compute
+// units a stream's blocks land on (CU-masked streams)
+hipError_t launch_cu_census(unsigned* out, int nblocks, int hold_us, hipStream_t s);
 // register-only MFMA stream on every SIMD (gemm.hip): d_frags = 9 x 64 x 8 halves, *flop = work of the launch
 hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s);
 

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const TIN* __restrict__ img
   const uint2 lo = pack4<T>(v[0], v[1], v[2], v[3]);
   const uint2 hi = pack4<T>(v[4], v[5], v[6], v[7]);
   o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-  reinterpret_cast<uint4*>(out)[idx] = o;
+  aux_store16(reinterpret_cast<uint4*>(out) + idx, o);
 }
 
 // Zero-padded 16-bit copy of an NCHW batch for the conv1 GEMM's patch gather when the convolution pads or its

@@ -247,6 +247,46 @@ def test_conv1_patch_gather_equals_im2col(cuda, dtype):
     assert 'im2col' not in names and 'gemm_conv1' in names
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_conv1_fp32_input_gathered_without_im2col(cuda, dtype):
+    """FP32 input — what the reference hands over (oadp/oake/globals.py:54-57: the transform's float32 crop,
+    `.cuda()`), and the headline bench's input: the conv1 GEMM's DMA waves fetch the patch rows with ordinary
+    loads, round them to the compute type and write the LDS image themselves.  Same rounding (RNE) and same
+    operand bits as the im2col route => bit-identical features; no `im2col` launch in the profile.  128 crops =
+    full tiles, 45 = a ragged last tile (row clamp), 300 = three passes; one crop = the small-problem fallback."""
+    sd = synthetic_state_dict()
+    direct, _ = clip.load(sd, compute_dtype=dtype, max_batch=128)
+    direct.visual.set_option('patch_direct', 2)  # opt-in: measured slower than im2col + GEMM with two lanes
+    via_im2col, _ = clip.load(sd, compute_dtype=dtype, max_batch=128)
+    via_im2col.visual.set_option('patch_direct', 0)
+    for n in (128, 45, 300, 1):
+        x = synthetic_images(n if n <= 128 else 100, seed=17 + n)
+        if n > 128:
+            x = x.repeat(3, 1, 1, 1)
+        x = x * 3.0 + 0.25  # values that do not sit on the fp16 grid
+        xd = x.to(cuda)
+        assert xd.dtype == torch.float32
+        a = direct.encode_image(xd, normalize=True, out_dtype=torch.float32)
+        b = via_im2col.encode_image(xd, normalize=True, out_dtype=torch.float32)
+        assert torch.equal(a, b), n
+        if n == 45:
+            ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x[:6]))
+            _check(a[:6], ref, *((1e-3, 1e-3) if dtype == torch.float16 else (2e-2, 8e-3)))
+    # a view whose base is not 16-byte aligned falls back to im2col and still agrees
+    buf = torch.zeros(64 * 3 * 224 * 224 + 1, device=cuda)
+    xs = synthetic_images(64, seed=3).to(cuda)
+    mis = buf[1:].view(64, 3, 224, 224)
+    mis.copy_(xs)
+    assert mis.data_ptr() % 16 != 0
+    assert torch.equal(direct.encode_image(mis, normalize=True), direct.encode_image(xs, normalize=True))
+    prof = direct.visual
+    prof.profile(True)
+    direct.encode_image(synthetic_images(64, seed=1).to(cuda))
+    names = {p_['name'] for p_ in prof.profile_read()}
+    prof.profile(False)
+    assert 'im2col' not in names and 'gemm_conv1' in names
+
+
 def test_batches_beyond_1024_crops_per_pass(cuda):
     """max_batch > 1024: the CLS rows of the last block (M = crops per pass) are then large enough for the
     persistent GEMM, which takes its LayerNorm statistics as per-row sums — decided per GEMM from the shape

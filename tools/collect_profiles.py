@@ -1,7 +1,7 @@
 """Copy the judged artefacts of a tools/profile_round.sh session from gpurun_out/<tag>/ (scratch) into
 profiles/<tag>/ (tracked) — raw tool output only — and derive, beside them, the per-launch HBM traffic
 table bench.py quotes (clearly marked as derived, with the session it came from).
-usage: python tools/collect_profiles.py [tag=r02]"""
+usage: python tools/collect_profiles.py [tag=r03]"""
 import collections
 import csv
 import glob
@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src, dst = ROOT / 'gpurun_out' / tag, ROOT / 'profiles' / tag
 dst.mkdir(parents=True, exist_ok=True)
 session = 'unknown'
@@ -28,6 +28,11 @@ NAMES = {'im2col_kernel': 'im2col', 'pad_nchw_kernel': 'pad_nchw', 'gemm_pp_kern
          'attention_pair_kernelIDF16_': 'attention', 'attention_coop_kernelIDF16_': 'attention',
          'embed_ln_pre_kernel': 'embed_ln_pre', 'crop_normalize_jobs_kernel': 'crop_normalize',
          'resample_h_kernel': 'resample_h', 'resample_v_kernel': 'resample_v'}
+
+
+# algorithmic bytes per launch of the kernel bench.py's `roofline` object names: A + W + output once
+# globals c_fc: M 12800 (256 crops x 50 tokens), N 3072, K 768, 16-bit: 19.66 + 4.72 + 78.64 MB
+ALGORITHMIC = {('globals', 'gemm_c_fc'): 2 * (12800 * 768 + 3072 * 768 + 12800 * 3072)}
 
 
 def per_kernel(path, counter):
@@ -70,6 +75,8 @@ for mode_dir in sorted(p for p in src.iterdir() if p.is_dir()):
                'hbm_bytes_per_launch': int((2 * f_kib + w_kib) * 1024)}
         for frag, slot in NAMES.items():
             if frag in k:
+                if (mode, slot) in ALGORITHMIC:
+                    rec['algorithmic_bytes_per_launch'] = ALGORITHMIC[(mode, slot)]
                 table[slot] = rec
     tagname = '' if mode == 'globals' else f'{mode}_'
     (ROOT / 'profiles' / f'{tag}_{tagname}hbm_traffic.json').write_text(json.dumps(table, indent=1))

@@ -1,13 +1,13 @@
 # Round profile session (GPU box): for each bench mode the driver-contract line, the rocprofv3
 # --kernel-trace --stats summary of the same command and separate PMC passes (FETCH_SIZE / WRITE_SIZE /
 # SQ), all RAW tool output, under gpurun_out/<tag>/<mode>/ ; plus a session stamp every derived number
-# carries.  usage: bash tools/profile_round.sh [tag=r02] [modes="globals blocks objects"]
+# carries.  usage: bash tools/profile_round.sh [tag=r03] [modes="globals blocks objects"]
 # Copy what is to be judged into profiles/<tag>/ afterwards (gpurun_out/ is scratch), then derive the
 # per-launch HBM traffic with tools/pmc_traffic.py (see the end of this file).
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 MODES=${2:-"globals blocks objects"}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 SESSION="$(hostname)-$(date -u +%Y%m%dT%H%M%SZ)"
@@ -19,10 +19,10 @@ for M in $MODES; do
   B="python $GRAFT_REPO_ROOT/bench.py --mode $M"
   (cd $GRAFT_REPO_ROOT && $B > $D/bench.json 2> $D/bench.err)
   cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o bench -- $B --steps 10 --warmup 3 --no-cpu-baseline > $D/bench_under_rocprof.json 2> $D/rocprof_stats.err
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $D/pmc_fetch.err
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $D/pmc_write.err
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $D/pmc_sq -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2> $D/pmc_sq.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o bench -- $B --steps 10 --warmup 3 --no-cpu-baseline --no-modes > $D/bench_under_rocprof.json 2> $D/rocprof_stats.err
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-modes > /dev/null 2> $D/pmc_fetch.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-modes > /dev/null 2> $D/pmc_write.err
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $D/pmc_sq -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-modes > /dev/null 2> $D/pmc_sq.err
   # keep what is judged, drop the bulky per-dispatch traces
   find $D -name "*kernel_trace.csv" -delete; find $D -name "*agent_info.csv" -delete
   cd $GRAFT_REPO_ROOT
