@@ -368,34 +368,30 @@ METRIC = {'globals': 'OAKE images/sec (ViT-B/32, 224^2, bs256)',
           'objects': 'OAKE images/sec (objects mode: proposal crops per image, dual-stream ViT-B/32)'}
 
 
-def _kernel_profile(model, work, one_lane_ms: float | None) -> tuple[dict, dict, dict]:
-    """Per-kernel durations of one step, from the kernels' own begin / end stamps on the launch stream.
-
-    Stamping EVERY launch perturbs the step: a stamped launch ends with the runtime's completion signal and
-    cache write-back, and the kernel behind it starts cold — the durations then add up to ~4 % more than an
-    un-instrumented one-lane step takes (round 2's W7).  So the reported numbers come from a SPARSE pass:
-    only every S-th launch is stamped (S prime, not dividing the launches per step), over S steps, so every
-    launch position is stamped exactly once and each stamped kernel runs behind un-instrumented predecessors,
-    as in the timed region.  The all-stamped sum is printed beside it."""
+def _kernel_profile(model, work, one_lane_ms: float | None, n_steps: int) -> tuple[dict, dict, dict]:
+    """Per-kernel durations of one step: every launch stamped with the kernel's own begin / end on the launch
+    stream (hipExtLaunchKernelGGL events), one lane, averaged over `n_steps` steps after one warm step under the
+    same instrumentation.  The wall clock of those very steps is taken too: the durations must add up to no more
+    than it (kernels of one stream do not overlap), and it is printed beside the un-instrumented one-lane step.
+    (Round 3 also tried stamping only every S-th launch, so that a stamped kernel runs behind un-instrumented
+    predecessors: the begin stamp of such a kernel is taken at dispatch, before its predecessor has drained, and
+    the durations then add up to MORE than the wall clock of the steps they were taken in — 21.2 vs 18.6 ms in
+    blocks mode, profiles/r03/globals/bench.json — so that form is not used.)"""
+    import torch
     v = model.visual
     v.profile(True)
-    work.step(model)
-    full = v.profile_read()
-    v.profile(False)
-    per_step = sum(p['seen'] for p in full)
-    stride = next(s for s in (7, 11, 13, 17, 19) if per_step % s)
-    import torch
-    v.profile(stride)
+    work.step(model)  # warm step under instrumentation, not recorded
+    v.profile(True)   # (resets the slots)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(stride):
+    for _ in range(n_steps):
         work.step(model)
     torch.cuda.synchronize()
-    stamped_wall_ms = (time.perf_counter() - t0) / stride * 1e3  # wall clock of the very steps that were stamped
+    stamped_wall_ms = (time.perf_counter() - t0) / n_steps * 1e3
     prof = [p for p in v.profile_read() if p['launches'] > 0]
     v.profile(False)
-    for p in prof:  # ms of ONE step: average stamped duration x launches per step
-        p['ms_per_step'] = p['total_ms'] / p['launches'] * (p['seen'] / stride)
+    for p in prof:
+        p['ms_per_step'] = p['total_ms'] / n_steps
         p['avg_us'] = p['total_ms'] / p['launches'] * 1e3
         p['flop_per_launch'] = p['flops'] / p['launches']
     gemms = [p for p in prof if p['flops'] > 0 and p['name'].startswith('gemm')]
@@ -408,23 +404,19 @@ def _kernel_profile(model, work, one_lane_ms: float | None) -> tuple[dict, dict,
         'avg_launch_us': round(dom['avg_us'], 2),
         'algorithmic_gflop_per_launch': round(dom['flop_per_launch'] / 1e9, 3),
         'timing': (f'live: HIP kernel begin/end stamps on the launch stream (hipExtLaunchKernelGGL events), one lane, '
-                   f'every {stride}th launch stamped over {stride} steps (each launch position once, behind '
-                   'un-instrumented predecessors)'),
+                   f'every launch of {n_steps} steps'),
         'traffic': None,
     }
     tot = sum(p['ms_per_step'] for p in prof)
     kernels = {p['name']: {'ms_per_step': round(p['ms_per_step'], 4), 'share': round(p['ms_per_step'] / tot, 4),
-                           'launches_per_step': round(p['seen'] / stride, 2),
+                           'launches_per_step': round(p['launches'] / n_steps, 2),
                            'tflops': round(p['flops'] / (p['total_ms'] * 1e-3) / 1e12, 1) if p['flops'] else None}
                for p in sorted(prof, key=lambda p: -p['ms_per_step'])}
     timing = {'kernels_sum_ms_per_step': round(tot, 4),
-              'one_lane_ms_per_step_while_stamping': round(stamped_wall_ms, 4),
+              'wall_ms_per_step_of_the_stamped_steps': round(stamped_wall_ms, 4),
               'one_lane_ms_per_step': None if one_lane_ms is None else round(one_lane_ms, 4),
-              'note': ('a stamped interval ends with the completion signal of that launch (~0.3 us that an '
-                       'un-instrumented kernel overlaps with its successor): the sum is bounded by the wall clock of '
-                       'the stamped steps themselves, and within ~1 % of the un-instrumented one-lane step'),
-              'all_launches_stamped_sum_ms_per_step': round(sum(p['total_ms'] for p in full), 4),
-              'launches_per_step': per_step, 'stamp_stride': stride}
+              'launches_per_step': round(sum(p['launches'] for p in prof) / n_steps, 1),
+              'consistent': bool(tot <= stamped_wall_ms and (one_lane_ms is None or tot <= one_lane_ms * 1.005))}
     return roofline, kernels, timing
 
 
@@ -462,7 +454,8 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
         # A/B switches (per model: oake_set_option on every lane's handle).  OAKE_CLS_LAST=0 runs the last
         # block for every token, as the reference does; OAKE_GEMM_VARIANT forces a GEMM tile configuration.
         for env, opt in (('OAKE_GEMM_VARIANT', 'gemm_variant'), ('OAKE_CLS_LAST', 'cls_last'),
-                         ('OAKE_ATTN_VARIANT', 'attention_variant'), ('OAKE_PATCH_DIRECT', 'patch_direct')):
+                         ('OAKE_ATTN_VARIANT', 'attention_variant'), ('OAKE_PATCH_DIRECT', 'patch_direct'),
+                         ('OAKE_GEMM_PANEL', 'gemm_panel')):
             if env in os.environ:
                 model.visual.set_option(opt, int(os.environ[env]))
         work.build(model)
@@ -549,7 +542,7 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
             sync()
             one_lane_ms = (time.perf_counter() - t1) / n1 * 1e3
             one_lane = round(work.units / one_lane_ms * 1e3, 1)
-        roofline, kernels, timing = _kernel_profile(model, work, one_lane_ms)
+        roofline, kernels, timing = _kernel_profile(model, work, one_lane_ms, 5 if args.mode == 'globals' else 2)
         # HBM bytes per launch cannot be sampled from inside this process: they come from separate
         # rocprofv3 --pmc passes over this same command (tools/pmc_traffic.py), committed under profiles/
         # together with the session they were measured in.  Reported only for the matching configuration

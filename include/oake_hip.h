@@ -272,12 +272,10 @@ OAKE_API int oake_jpeg_reconstruct(oake_handle* h, const uint8_t* h_data, size_t
  * Per-kernel timing with HIP events on the launch stream (bench.py's `roofline` object).
  * enable=1 brackets every kernel launch with events; oake_profile_read synchronises and
  * returns, for up to `cap` kernel slots, name / total milliseconds / launch count / flops.
- * enable=S > 1 stamps only every S-th launch (counted over all kernels since the call): a stamped
- * launch ends with a completion signal and a cache write-back that the kernel after it pays for, so
- * with every launch stamped the durations add up to more than an un-instrumented step takes; sampled
- * sparsely over S steps (S not dividing the launches per step) every launch position is stamped once,
- * each behind un-instrumented predecessors.  `launches` counts the stamped launches (what total_ms,
- * flops and bytes cover), `seen` all launches since the reset.
+ * enable=S > 1 stamps only every S-th launch (counted over all kernels since the call).  `launches` counts the
+ * stamped launches (what total_ms, flops and bytes cover), `seen` all launches since the reset.  Caveat, measured:
+ * the begin stamp of a kernel whose predecessor carries no stamp is taken at dispatch, before that predecessor has
+ * drained — sparse durations can add up to MORE than the wall clock; bench.py stamps every launch.
  * Profiling perturbs launches — never leave it on inside a throughput measurement.
  */
 typedef struct oake_profile_entry {

@@ -96,6 +96,13 @@ struct TileMap {
 #ifndef OAKE_STORE_POLICY_PARTIAL
 #define OAKE_STORE_POLICY_PARTIAL 0
 #endif
+// Measurement build (-DOAKE_TRICKLE_FULLLINE=1): the trickled pieces of the pure-store epilogues (qkv) lane-swapped
+// into full lines at pack time and written through as well.  Neutral in all three modes (110.1 vs 109.9 k images/s,
+// 82.0 vs 82.0 images/s objects, 3900 vs 3899 blocks: profiles/r03/ab_session_i_trickle_fullline_*.log): the 40 DPP
+// moves per tile cost what the merged lines save; production keeps the accumulator layout + plain stores.
+#ifndef OAKE_TRICKLE_FULLLINE
+#define OAKE_TRICKLE_FULLLINE 0
+#endif
 template <typename P>
 __device__ __forceinline__ void tile_store16(P* p, u32x4_t v) {  // full-line instruction
   store16_policy<OAKE_STORE_POLICY>(p, v);
@@ -494,6 +501,19 @@ __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&p
         pend[mi - MI0][t] = pk;
     }
   }
+#if OAKE_TRICKLE_FULLLINE
+  // the pending pieces leave as FULL lines (and can then be written through, see OAKE_STORE_POLICY): lanes r and
+  // r ^ 8 swap one piece each, exactly as the lane-swapped stores of tile_epilogue_impl — piece [mi][0] becomes
+  // (row 16 mi + (r & 7), columns 32 (r >> 3) + 8 g ..), piece [mi][1] the same columns 8 rows further down
+  static_assert(NP == 2, "piece swap pairs the two 32-column halves of a wave's 64 columns");
+#pragma unroll
+  for (int mi = MI0; mi < MI; ++mi) {
+    const u32x4_t a = as_u32x4(pend[mi - MI0][0]), b = as_u32x4(pend[mi - MI0][1]);
+    const u32x4_t sa = swap_piece(a, b, true), sb = swap_piece(b, a, false);
+    pend[mi - MI0][0] = make_uint4(sa[0], sa[1], sa[2], sa[3]);
+    pend[mi - MI0][1] = make_uint4(sb[0], sb[1], sb[2], sb[3]);
+  }
+#endif
 }
 
 template <typename T, int EPI, int MI, int NI>
@@ -1233,9 +1253,16 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   uint4 pend[TRICKLE ? MI - MI0 : 1][TRICKLE ? NI / 2 : 1];
   T* pend_ptr = nullptr;  // lane's address of the tile's first row-block (mi = 0, t = 0)
   int pend_next = NPEND;  // next pending piece to store (NPEND = none)
+#if OAKE_TRICKLE_FULLLINE
+  // (pend_ptr = the lane's address of piece [0][0] in the swapped form: row r & 7, columns 32 (r >> 3) + 8 g)
+#define OAKE_STORE_PEND(i_)                                                                  \
+  tile_store16(pend_ptr + (size_t)(((i_) / (NI / 2) + MI0) * 16 + ((i_) % (NI / 2)) * 8) * ep.ldo, \
+               as_u32x4(pend[(i_) / (NI / 2)][(i_) % (NI / 2)]))
+#else
 #define OAKE_STORE_PEND(i_)                                                                  \
   tile_store16_partial(pend_ptr + (size_t)((i_) / (NI / 2) + MI0) * 16 * ep.ldo + ((i_) % (NI / 2)) * 32, \
                as_u32x4(pend[(i_) / (NI / 2)][(i_) % (NI / 2)]))
+#endif
 
   const unsigned long long t_entry = trace ? __builtin_readcyclecounter() : 0;
   if (trace != nullptr && tid == 0) trace[4096 + blockIdx.x * 2] = wall_clock64();
@@ -1320,6 +1347,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
                        wn * TN + 8 * fg;
             tile_pack_paired<T, EPI, MI, NI, MI0>(acc, pend, ep, pend_ptr, elds, wn * TN + 8 * fg,
                                                   wm * TM + frow);
+#if OAKE_TRICKLE_FULLLINE
+            pend_ptr += (ptrdiff_t)((frow & 7) - frow) * ep.ldo + ((frow & 8) ? 32 : 0);
+#endif
             pend_next = 0;
             deferred = true;
           }

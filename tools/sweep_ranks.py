@@ -17,21 +17,28 @@ from oadp_amd.weights import synthetic_state_dict
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 which = sys.argv[2] if len(sys.argv) > 2 else 'blocks'
 rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
 if world > 1:
     td.init_process_group(backend='gloo')
 root = pathlib.Path(sys.argv[3] if len(sys.argv) > 3 else os.path.join(tempfile.gettempdir(), f'oake_ranks_{n}'))
+def _make(args):
+    path, i = args
+    w, h = (640, 480) if i % 3 else (480, 640)
+    rng = np.random.default_rng(i)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = (rng.integers(0, 24, (h, w, 3)) + np.stack([(xx * 3 + yy + i) % 200, (xx + yy * 2) % 200, (xx * yy // 7) % 200], -1)).astype(np.uint8)
+    Image.fromarray(a).save(path, quality=85, subsampling=2)
+
+
 if rank == 0 and not (root / 'ann.json').exists():
+    from multiprocessing import Pool
     (root / 'images').mkdir(parents=True, exist_ok=True)
     rng = np.random.default_rng(0)
     images, props = [], []
+    with Pool(min(64, os.cpu_count() or 8)) as pool:  # (before any HIP call of this process: fork is safe)
+        pool.map(_make, [(str(root / 'images' / f'{i:012d}.jpg'), i) for i in range(n)], chunksize=64)
     for i in range(n):
         w, h = (640, 480) if i % 3 else (480, 640)
-        yy, xx = np.mgrid[0:h, 0:w]
-        a = (rng.integers(0, 24, (h, w, 3)) + np.stack([(xx * 3 + yy + i) % 200, (xx + yy * 2) % 200, (xx * yy // 7) % 200], -1)).astype(np.uint8)
-        name = f'{i:012d}.jpg'
-        Image.fromarray(a).save(root / 'images' / name, quality=85, subsampling=2)
-        images.append(dict(id=i, file_name=name, width=w, height=h))
+        images.append(dict(id=i, file_name=f'{i:012d}.jpg', width=w, height=h))
         x1 = rng.uniform(0, w * 0.7, 300); y1 = rng.uniform(0, h * 0.7, 300)
         bw = np.exp(rng.uniform(np.log(8), np.log(min(w, h)), 300)); bh = np.exp(rng.uniform(np.log(8), np.log(min(w, h)), 300))
         sc = np.sort(rng.uniform(0, 1, 300))[::-1]
@@ -41,6 +48,7 @@ if rank == 0 and not (root / 'ann.json').exists():
     (root / 'ann.json').write_text(json.dumps(dict(images=images, annotations=[], categories=[])))
 if world > 1:
     td.barrier()
+torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
 out = root / f'out_{which}_{world}'
 if rank == 0:
     shutil.rmtree(out, ignore_errors=True)
@@ -66,16 +74,27 @@ else:
 torch.cuda.synchronize()
 if world > 1:
     td.barrier()
+# host load while the sweep runs (rank 0 samples the whole box: the question is how many ranks the HOST carries)
+cpu_samples, stop = [], [False]
+if rank == 0:
+    import threading, psutil
+    def _sample():
+        psutil.cpu_percent(None)
+        while not stop[0]:
+            cpu_samples.append(psutil.cpu_percent(0.25))
+    threading.Thread(target=_sample, daemon=True).start()
 t0 = time.perf_counter()
 c = v.run()
 torch.cuda.synchronize()
 if world > 1:
     td.barrier()
 dt = time.perf_counter() - t0
+stop[0] = True
 per_rank = gather_counters(c, torch.device('cpu'))
 if rank == 0:
     images = sum(r[0] for r in per_rank); crops = sum(r[1] for r in per_rank)
     print(f'{which:8s} {world} rank(s) on one GPU: {int(images)} images, {int(crops)} crops in {dt:.2f} s = '
-          f'{images / dt:.0f} images/s, {crops / dt:.0f} crops/s', flush=True)
+          f'{images / dt:.0f} images/s, {crops / dt:.0f} crops/s; host CPU {sum(cpu_samples) / max(len(cpu_samples), 1):.1f} % of '
+          f'{os.cpu_count()} logical cores (mean of {len(cpu_samples)} samples)', flush=True)
 if world > 1:
     td.destroy_process_group()
