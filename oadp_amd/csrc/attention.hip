@@ -299,7 +299,7 @@ void attention_pair_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       if (row < L)
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src0 + (size_t)row * ld + chunk * 8),
-                                         (lds_ptr_t)(dst + jr * 1024), 16, 0, 0);
+                                         (lds_ptr_t)(dst + jr * 1024), 16, 0, OAKE_STREAM_AUX);
     }
   }
   // Q fragments (B operand): Q[q0 + 16 mt + fr][32 kk + 8 g .. +8), as full lines (common.h, swap_piece)
@@ -311,8 +311,8 @@ void attention_pair_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L
       int ra = q0 + mt * 16 + sw_row, rb = ra + 8;
       ra = ra < L ? ra : L - 1;
       rb = rb < L ? rb : L - 1;
-      const vec8 pa = *reinterpret_cast<const vec8*>(base + (size_t)ra * ld + sw_col);
-      const vec8 pb = *reinterpret_cast<const vec8*>(base + (size_t)rb * ld + sw_col);
+      const vec8 pa = stream_load16(reinterpret_cast<const vec8*>(base + (size_t)ra * ld + sw_col));
+      const vec8 pb = stream_load16(reinterpret_cast<const vec8*>(base + (size_t)rb * ld + sw_col));
       qf[mt][0] = swap_piece(pa, pb, true);
       qf[mt][1] = swap_piece(pb, pa, false);
     }

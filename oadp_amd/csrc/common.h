@@ -196,6 +196,21 @@ __device__ __forceinline__ void aux_store16(P* p, uint4 v) {
   store16_policy<OAKE_AUX_STORE_POLICY>(p, as_u32x4(v));
 }
 
+// Loads of data that is read exactly once by exactly one CU (attention's q / k / v rows): measurement switch
+// -DOAKE_STREAM_AUX=2 marks them non-temporal so that they do not displace the other lane's weight panels from the
+// L2s; 0 = default policy.
+#ifndef OAKE_STREAM_AUX
+#define OAKE_STREAM_AUX 0
+#endif
+template <typename V>
+__device__ __forceinline__ V stream_load16(const V* p) {
+#if OAKE_STREAM_AUX == 2
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 // QuickGELU (OpenAI CLIP): x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)).
 // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division: the result is rounded to 16 bits
 // right after, and the c_fc epilogue evaluates this 80 times per lane per tile.

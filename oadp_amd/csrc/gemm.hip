@@ -1792,8 +1792,8 @@ hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
 
 // Configurations.  0: simple 128x128 (4 waves)   1: simple 160x256 (8 waves 2x4)
 //                  2: simple 320x128 (8 waves 4x2)   3: simple 256x256 (8 waves 2x4)
-//                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production; the residual and conv1
-//                     epilogues run the K loop in two long phases per K-tile, the others in four]
+//                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production; the residual, conv1 and
+//                     LayerNorm-folded (qkv, c_fc) epilogues run the K loop in two long phases per K-tile, the others in four]
 //                  8: the same at 128x256 (experiment)   9: two long phases wherever they fit   10: four phases everywhere
 //                  5: deep-ring 64x64 (4 waves, 4-slot ring) for the few-hundred-row problems (head,
 //                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
@@ -1821,6 +1821,11 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
       // beat four phases + trickled stores there (+1.1 % on the bench, A/B of two builds in one session; for
       // qkv's lighter epilogue the same switch is neutral: it keeps the trickled stores)
       else if constexpr (EPI == EPI_T16_GELU_LN)
+        return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+      // ... and, with the tile stores written through (round 3), for qkv's too: all of a tile's stores at its end
+      // as full lines, nothing left dirty in the L2s — +0.7 % globals, +0.4 % blocks, +0.2 % objects
+      // (profiles/r03/ab_session_k_*; before the write-through stores the same switch was neutral)
+      else if constexpr (EPI == EPI_T16_BIAS_LN)
         return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
       else
         return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
