@@ -196,11 +196,13 @@ __device__ __forceinline__ void aux_store16(P* p, uint4 v) {
   store16_policy<OAKE_AUX_STORE_POLICY>(p, as_u32x4(v));
 }
 
-// Loads of data that is read exactly once by exactly one CU (attention's q / k / v rows): measurement switch
-// -DOAKE_STREAM_AUX=2 marks them non-temporal so that they do not displace the other lane's weight panels from the
-// L2s; 0 = default policy.
+// Loads of data that is read exactly once by exactly one CU (the L <= 64 attention's q / k / v rows): marked
+// non-temporal (aux 2 / __builtin_nontemporal_load) so that 59 MB of them per launch do not displace the weight
+// panels and activation slabs the OTHER lane's GEMM keeps in the L2s.  One lane: neutral (96.7 vs 96.9 k images/s);
+// two lanes: +0.75 % (111.3 vs 110.5 k, four interleaved rounds, profiles/r03/ab_session_m_attention_nt.log).
+// -DOAKE_STREAM_AUX=0 = default policy (A/B builds).
 #ifndef OAKE_STREAM_AUX
-#define OAKE_STREAM_AUX 0
+#define OAKE_STREAM_AUX 2
 #endif
 template <typename V>
 __device__ __forceinline__ V stream_load16(const V* p) {

@@ -93,6 +93,12 @@ struct TileMap {
 // written by different instructions (or K-tiles apart) and only a write-back L2 merges them into one line
 // (written through, they were -1.9 % in objects mode, where a kernel has 15 tiles per CU and its end-of-kernel
 // release hardly matters: profiles/r03/ab_session_g_store_policy_objects.log).
+// measurement switch: cache policy bits of the A operand's LDS-DMA pieces (2 = nt; activations are read by the few
+// tiles of one N panel and never again, the W panel by every tile).  Measured: -8.6 % (102.4 vs 112.1 k images/s,
+// profiles/r03/ab_session_n_gemm_a_operand_nt.log) — the panel's tiles do re-read their A rows from the L2.
+#ifndef OAKE_GEMM_A_AUX
+#define OAKE_GEMM_A_AUX 0
+#endif
 #ifndef OAKE_STORE_POLICY_PARTIAL
 #define OAKE_STORE_POLICY_PARTIAL 0
 #endif
@@ -103,6 +109,18 @@ struct TileMap {
 #ifndef OAKE_TRICKLE_FULLLINE
 #define OAKE_TRICKLE_FULLLINE 0
 #endif
+// measurement switch: the residual tile (read once, by the one tile that owns it) with non-temporal loads
+#ifndef OAKE_RESID_NT
+#define OAKE_RESID_NT 0
+#endif
+template <typename V>
+__device__ __forceinline__ V resid_load16(const V* p) {
+#if OAKE_RESID_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 template <typename P>
 __device__ __forceinline__ void tile_store16(P* p, u32x4_t v) {  // full-line instruction
   store16_policy<OAKE_STORE_POLICY>(p, v);
@@ -285,8 +303,8 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
       const int _m = mbase + (mi_) * 16 + (SWAP ? swap_row + 8 * _t : 0);                       \
       const int _n = nwave + 8 * g + (SWAP ? swap_col : 32 * _t);                               \
       if (FULL || (_m < M && _n < N))                                                           \
-        xres[mi_][_t] = *reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(ep.out) +     \
-                                                       (size_t)_m * ep.ldo + _n);               \
+        xres[mi_][_t] = resid_load16(reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(ep.out) + \
+                                                                   (size_t)_m * ep.ldo + _n));  \
     }                                                                                           \
   } while (0)
     if constexpr (EPI == EPI_RESID16) {
@@ -1071,9 +1089,14 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       const size_t _koff = (size_t)s_kt * (BK * 2);                                          \
       const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P, ep.patch_H) : _koff; \
       _Pragma("unroll") for (int _j = (j0_); _j < (j1_); ++_j)                               \
-          if (!A32 || _j >= kAPieces)                                                        \
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
-                                             (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0); \
+          if (!A32 || _j >= kAPieces) {                                                      \
+            if (_j < kAPieces)                                                               \
+              __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koffa),                \
+                                               (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, OAKE_GEMM_A_AUX); \
+            else                                                                             \
+              __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                 \
+                                               (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0); \
+          }                                                                                  \
     }                                                                                        \
   } while (0)
 #define OAKE_ADVANCE()                                    \

@@ -201,9 +201,17 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(TX* __restrict__ x,
 }
 
 // ---- im2col -----------------------------------------------------------------------------
+// (measurement switch -DOAKE_IM2COL_NT=1: the input batch is read once — non-temporal loads)
+#ifndef OAKE_IM2COL_NT
+#define OAKE_IM2COL_NT 0
+#endif
 template <typename TIN>
 __device__ __forceinline__ float load_px(const TIN* p) {
+#if OAKE_IM2COL_NT
+  return (float)__builtin_nontemporal_load(p);
+#else
   return (float)(*p);
+#endif
 }
 
 template <typename T, typename TIN>
