@@ -1,6 +1,8 @@
+# Validator ranks sharing ONE GPU, files -> .pth (globals: 1/2/4/8 ranks; blocks: 1/4) with host CPU %: how many ranks
+# the host carries per GPU.  usage: bash tools/hostfeed_ranks.sh [out dir]   (GPU box)
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03i; mkdir -p $O
+O=${1:-gpurun_out/hostfeed}; mkdir -p $O
 N=32768
 for R in 1 2 4 8; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port $((29600+R)) tools/sweep_ranks.py $N globals /tmp/oake_ranks_$N 2>&1 | grep "rank(s) on one GPU" | tee -a $O/hostfeed_globals.log
