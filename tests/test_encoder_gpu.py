@@ -437,3 +437,51 @@ def test_objects_conv1_from_padded_buffer_equals_im2col(cuda, in_dtype):
     sd2['visual.positional_embedding'] = a.positional_embedding.detach().cpu().float()
     ref = l2_normalize(encode_objects_ref(sd2, ViTConfig(stride=16, padding=15), x[:4].cpu().float(), masks[:4].cpu().float()))
     _check(ya[:4], ref, 1e-3, 1e-3)
+
+
+def test_cu_count_option_and_masked_stream(cuda, lib):
+    """OAKE_OPT_CU_COUNT sizes the persistent grids for a CU-masked stream (round 3's half-chip lanes experiment,
+    oadp_amd/cumask.py): fewer, longer-running blocks walk the same tiles — bit-identical features — and a stream
+    created over the first half of the mask bits really runs on half of the CUs, half of EVERY XCD."""
+    import ctypes as C
+    from oadp_amd import cumask
+    sd = synthetic_state_dict()
+    full, _ = clip.load(sd, max_batch=64)
+    half, _ = clip.load(sd, max_batch=64)
+    half.visual.set_option('cu_count', 128)
+    x = synthetic_images(64, seed=91).half().to(cuda)  # 3200 rows: the persistent kernels
+    want = full.encode_image(x, normalize=True, out_dtype=torch.float32)
+    ncu = torch.cuda.get_device_properties(cuda).multi_processor_count
+    masks = cumask.half_masks(ncu, 'halves')
+    stream = torch.cuda.ExternalStream(cumask.create_masked_stream(masks[0]), device=cuda)
+    with torch.cuda.stream(stream):
+        got = half.encode_image(x, normalize=True, out_dtype=torch.float32)
+    stream.synchronize()
+    assert torch.equal(got, want)
+    out = torch.zeros((512, 2), dtype=torch.int32, device=cuda)
+    assert lib.oake_debug_cu_census(out.data_ptr(), 512, 200, C.c_void_p(stream.cuda_stream)) == 0
+    stream.synchronize()
+    o = out.cpu().numpy().astype('uint32')
+    seen = {(int(xcc) & 15, (int(hw) >> 13) & 7, (int(hw) >> 12) & 1, (int(hw) >> 8) & 15) for xcc, hw in o}
+    per_xcc = {}
+    for k in seen:
+        per_xcc[k[0]] = per_xcc.get(k[0], 0) + 1
+    assert len(seen) == ncu // 2 and len(per_xcc) == 8 and set(per_xcc.values()) == {ncu // 16}, per_xcc
+
+
+def test_profiler_counts_stamped_and_seen_launches(cuda):
+    sd = synthetic_state_dict(**TINY)
+    model, _ = clip.load(sd, max_batch=8)
+    x = synthetic_images(4, seed=3).to(cuda)
+    model.encode_image(x)
+    v = model.visual
+    v.profile(True)
+    model.encode_image(x)
+    full = v.profile_read()
+    assert full and all(p['launches'] == p['seen'] >= 1 and p['total_ms'] > 0 for p in full)
+    n = sum(p['seen'] for p in full)
+    v.profile(3)  # every third launch stamped
+    model.encode_image(x)
+    sparse = v.profile_read()
+    v.profile(False)
+    assert sum(p['seen'] for p in sparse) == n and sum(p['launches'] for p in sparse) == (n + 2) // 3
