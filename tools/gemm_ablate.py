@@ -17,7 +17,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 MODES = (('bias', 0), ('gelu', 1), ('raw', 3), ('none', 2))
 m = 12800
-for name, n, k in (('c_fc', 3072, 768), ('qkv', 2304, 768), ('c_proj', 768, 3072)):
+for name, n, k in (('c_fc', 3072, 768), ('qkv', 2304, 768), ('out_proj', 768, 768), ('c_proj', 768, 3072)):
     a = (torch.randn(m, k, device=dev) * 0.5).half()
     w = (torch.randn(n, k, device=dev) * k ** -0.5).half()
     bias = torch.randn(n, device=dev)
