@@ -347,20 +347,113 @@ def _sustained_mfma(dev, seconds: float = 1.2) -> dict:
     return out
 
 
+class _BoardWatch:
+    """Board power / shader clock while a loop runs: a thread that samples the amdgpu hwmon files of the device
+    (power1_average | power1_input in microwatts, freq1_input in Hz) every 100 ms, or — where the box does not
+    expose them — `rocm-smi --showpower --showclocks --json` as often as it returns."""
+
+    def __init__(self, device_index: int = 0) -> None:
+        import glob
+        import threading
+        self.power, self.sclk, self.source = [], [], None
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
+        self._hw = None
+        if cards:
+            hw = cards[min(device_index, len(cards) - 1)]
+            pw = [f for f in (f'{hw}/power1_average', f'{hw}/power1_input') if os.path.exists(f)]
+            fq = f'{hw}/freq1_input' if os.path.exists(f'{hw}/freq1_input') else None
+            if pw:
+                self._hw, self.source = (pw[0], fq), 'sysfs hwmon (power1, freq1)'
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _sample_smi(self) -> None:
+        try:
+            out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--json'], capture_output=True,
+                                 text=True, timeout=5).stdout
+            card = next(iter(json.loads(out).values()))
+            for k, v in card.items():
+                if 'power' in k.lower() and 'w' in k.lower():
+                    self.power.append(float(v))
+                    break
+            for k, v in card.items():
+                if k.lower().startswith('sclk clock speed'):
+                    self.sclk.append(float(''.join(c for c in str(v) if c.isdigit() or c == '.')))
+                    break
+            self.source = 'rocm-smi'
+        except Exception:
+            pass
+
+    def _run(self) -> None:
+        while not self._stop.is_set():
+            if self._hw is not None:
+                try:
+                    self.power.append(int(open(self._hw[0]).read()) / 1e6)
+                    if self._hw[1]:
+                        self.sclk.append(int(open(self._hw[1]).read()) / 1e6)
+                except (OSError, ValueError):
+                    pass
+                self._stop.wait(0.1)
+            else:
+                self._sample_smi()
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self._stop.set()
+        self._thread.join(timeout=6)
+
+    def summary(self) -> dict:
+        def med(v):
+            v = sorted(v)
+            return round(v[len(v) // 2], 1) if v else None
+        return {'power_w_median': med(self.power), 'power_w_max': round(max(self.power), 1) if self.power else None,
+                'sclk_mhz_median': med(self.sclk), 'samples': max(len(self.power), len(self.sclk)), 'source': self.source}
+
+
+def _sustained(step, sync, units_per_step: int, seconds: float, dev_index: int) -> dict:
+    """>= `seconds` of back-to-back steps AFTER the contract's timed region (the K timed steps of the headline
+    take tens of milliseconds): the rate the same loop holds once clocks and temperature have settled, with the
+    board's power and shader clock sampled beside it.  The headline fields are not touched by this."""
+    chunk, n = 100, 0
+    with _BoardWatch(dev_index) as watch:
+        sync()
+        t0 = time.perf_counter()
+        while True:
+            for _ in range(chunk):
+                step()
+            n += chunk
+            sync()
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+    rate = units_per_step * n / dt
+    return {'value_sustained': round(rate, 3 if rate < 100 else 1), 'unit': 'images/sec', 'seconds': round(dt, 2),
+            'steps': n, 'ms_per_step': round(dt / n * 1e3, 4), **watch.summary(),
+            'what': f'{n} back-to-back steps (same lanes as the timed region, one host sync per {chunk} steps) run '
+                    'right after the timed region'}
+
+
 WORKS = {'globals': GlobalsWork, 'blocks': BlocksWork, 'objects': ObjectsWork}
 DEFAULT_BATCH = {'globals': 256, 'blocks': 64, 'objects': 8}
 DEFAULT_MAX_BATCH = {'globals': None, 'blocks': 512, 'objects': 512}
 
 
-def _profile_files(mode: str) -> tuple[str, str]:
-    """The committed rocprofv3 artefacts of the newest round that has them (profiles/rNN_*)."""
-    tag = '' if mode == 'globals' else f'{mode}_'
-    for rnd in ('r03', 'r02'):
-        t = os.path.join(ROOT, 'profiles', f'{rnd}_{tag}hbm_traffic.json')
-        if os.path.exists(t):
-            return t, os.path.join(ROOT, 'profiles', f'{rnd}_{tag}rocprofv3_kernel_stats.csv')
-    return (os.path.join(ROOT, 'profiles', f'r02_{tag}hbm_traffic.json'),
-            os.path.join(ROOT, 'profiles', f'r02_{tag}rocprofv3_kernel_stats.csv'))
+def _committed_profile(mode: str, slot: str) -> dict | None:
+    """The newest committed ONE-LANE profile record of kernel `slot` in `mode`: profiles/rNN_mfma_util_hbm.json,
+    derived by tools/derive_counters.py from the raw rocprofv3 passes under profiles/rNN/<mode>/ (kernel trace for
+    the launch duration, separate --pmc FETCH_SIZE / WRITE_SIZE / SQ passes).  One lane = the condition the live
+    per-kernel stamps below are taken under."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_mfma_util_hbm.json')), reverse=True):
+        tj = json.load(open(path))
+        rec = tj.get(mode, {}).get(slot)
+        if rec:
+            return dict(rec, _file=os.path.relpath(path, ROOT), _session=tj.get('_session', 'unknown'),
+                        _raw=tj[mode].get('_derived_from'))
+    return None
 
 
 METRIC = {'globals': 'OAKE images/sec (ViT-B/32, 224^2, bs256)',
@@ -406,6 +499,7 @@ def _kernel_profile(model, work, one_lane_ms: float | None, n_steps: int) -> tup
         'timing': (f'live: HIP kernel begin/end stamps on the launch stream (hipExtLaunchKernelGGL events), one lane, '
                    f'every launch of {n_steps} steps'),
         'traffic': None,
+        '_dom': {'flop_per_launch': dom['flop_per_launch']},
     }
     tot = sum(p['ms_per_step'] for p in prof)
     kernels = {p['name']: {'ms_per_step': round(p['ms_per_step'], 4), 'share': round(p['ms_per_step'] / tot, 4),
@@ -528,6 +622,16 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
     else:
         total_units, total_crops, ranks_seen = counters[0].item(), counters[1].item(), 1
 
+    # the same loop for >= 2 s (headline line at N = 1 only; OAKE_BENCH_SUSTAINED_S=0 skips it)
+    sustained = None
+    sus_s = float(os.environ.get('OAKE_BENCH_SUSTAINED_S', 2.5))
+    if rank == 0 and world == 1 and not sub and not DRY_PLUMBING and not args.no_profile and sus_s > 0:
+        sustained = _sustained(step, sync, work.units, sus_s, dev.index or 0)
+
+    if cu_split and n_lanes == 2 and not DRY_PLUMBING:
+        # the one-lane and per-kernel sections below run on the current, UNMASKED stream: full-chip grids again
+        model.visual.set_option('cu_count', 0)
+
     roofline = kernels = timing = None
     one_lane = one_lane_ms = None
     if rank == 0 and not args.no_profile and not DRY_PLUMBING:
@@ -547,27 +651,25 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
         # rocprofv3 --pmc passes over this same command (tools/pmc_traffic.py), committed under profiles/
         # together with the session they were measured in.  Reported only for the matching configuration
         # and always labelled as not-live.
-        tpath, spath = _profile_files(args.mode)
         default_cfg = (args.batch == DEFAULT_BATCH[args.mode] and args.dtype == 'f16'
                        and args.image_size == '640x480' and args.proposals == 300)
-        if os.path.exists(tpath) and default_cfg:
-            tj = json.load(open(tpath))
-            rec = tj.get(roofline['kernel'])
-            if rec:
+        rec = _committed_profile(args.mode, roofline['kernel']) if default_cfg else None
+        if rec:
+            src = {'file': rec['_file'], 'raw': rec['_raw'], 'live': False, 'session': rec['_session'], 'lanes': 1}
+            if rec.get('hbm_bytes_per_launch'):
                 roofline['traffic'] = rec['hbm_bytes_per_launch']
                 roofline['traffic_unit'] = 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)'
                 if rec.get('algorithmic_bytes_per_launch'):
                     roofline['traffic_over_algorithmic'] = round(
                         rec['hbm_bytes_per_launch'] / rec['algorithmic_bytes_per_launch'], 3)
-                roofline['traffic_source'] = {'file': os.path.relpath(tpath, ROOT), 'live': False,
-                                              'session': tj.get('_session', 'unknown')}
-                if os.path.exists(spath) and rec.get('kernel'):
-                    import csv
-                    for row in csv.DictReader(open(spath)):
-                        if row['Name'] == rec['kernel']:
-                            roofline['avg_launch_us_rocprofv3'] = round(float(row['AverageNs']) / 1e3, 2)
-                            roofline['rocprofv3_summary'] = {'file': os.path.relpath(spath, ROOT), 'live': False,
-                                                             'session': tj.get('_session', 'unknown')}
+                roofline['hbm_gbps'] = rec.get('hbm_gbps')
+                roofline['traffic_source'] = src
+            roofline['avg_launch_us_rocprofv3'] = rec['avg_launch_us_rocprofv3']
+            roofline['frac_rocprofv3'] = round(dom['flop_per_launch'] / (rec['avg_launch_us_rocprofv3'] * 1e-6)
+                                               / PEAK_MFMA_DENSE, 4) if (dom := roofline.get('_dom')) else None
+            roofline['mfma_util_at_clock_pmc'] = rec.get('mfma_util_at_clock')
+            roofline['rocprofv3_summary'] = src
+        roofline.pop('_dom', None)
         if world == 1 and args.dtype == 'f16' and not sub:
             sus = _sustained_mfma(dev)
             roofline['sustained'] = {
@@ -608,6 +710,7 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
                                         if roofline and roofline.get('sustained') else None),
             'flop_per_crop': {'model': work.flop_model_per_crop, 'executed': flop_crop},
             'one_lane_images_per_sec': one_lane,
+            'sustained': sustained,
             'roofline': roofline,
             'kernel_timing': timing,
             'kernels': kernels,

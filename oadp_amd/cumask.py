@@ -47,10 +47,12 @@ def create_masked_stream(mask_words: list[int]) -> int:
     return s.value
 
 
-def half_masks(n_cus: int, scheme: str = 'pairs') -> list[list[int]]:
-    """Two complementary masks over n_cus compute units.  scheme: 'halves' = bits [0, n/2) / [n/2, n);
-    'even_odd' = even / odd bits; 'pairs' = (i // 8) even / odd ...  Which of them splits every XCD in two
-    depends on how the driver enumerates CUs (tools/cu_mask_probe.py)."""
+def half_masks(n_cus: int, scheme: str = 'halves') -> list[list[int]]:
+    """Two complementary masks over n_cus compute units.  scheme: 'halves' = bits [0, n/2) / [n/2, n) (the default:
+    with mask bit i = XCD i % 8, CU i / 8 — tools/cu_mask_probe.py — that is half of EVERY XCD per lane);
+    'even_odd' = even / odd bits; 'group<N>' = (i // N) even / odd ('pairs' is an alias of 'group8')."""
+    if scheme == 'pairs':
+        scheme = 'group8'
     def words(bits):
         w = [0] * ((n_cus + 31) // 32)
         for b in bits:

@@ -5,6 +5,8 @@ import pathlib
 import re
 import subprocess
 
+import pytest
+
 from oadp_amd import _lib
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
@@ -71,3 +73,17 @@ def test_no_cpu_fallback_in_product():
         assert 'no CPU fallback' in str(e)
     else:
         raise AssertionError('CPU tensor was accepted')
+
+
+def test_cu_half_masks_are_complementary_and_default_exists():
+    """half_masks() default scheme must exist; the two masks partition the CUs."""
+    from oadp_amd import cumask
+    for scheme in (None, 'halves', 'even_odd', 'group8', 'pairs', 'group4'):
+        a, b = cumask.half_masks(256) if scheme is None else cumask.half_masks(256, scheme)
+        assert len(a) == len(b) == 8
+        for wa, wb in zip(a, b):
+            assert wa & wb == 0 and (wa | wb) == 0xFFFFFFFF
+        assert sum(bin(w).count('1') for w in a) == 128
+    assert cumask.half_masks(256, 'pairs') == cumask.half_masks(256, 'group8')
+    with pytest.raises(ValueError):
+        cumask.half_masks(256, 'nonsense')

@@ -1,35 +1,40 @@
-# Round profile session (GPU box): for each bench mode the driver-contract line, the rocprofv3
-# --kernel-trace --stats summary of the same command and separate PMC passes (FETCH_SIZE / WRITE_SIZE /
-# SQ), all RAW tool output, under gpurun_out/<tag>/<mode>/ ; plus a session stamp every derived number
-# carries.  usage: bash tools/profile_round.sh [tag=r03] [modes="globals blocks objects"]
-# Copy what is to be judged into profiles/<tag>/ afterwards (gpurun_out/ is scratch), then derive the
-# per-launch HBM traffic with tools/pmc_traffic.py (see the end of this file).
+# Round profile session (GPU box): for each bench mode the driver-contract line (two lanes, as the driver runs it),
+# then — on ONE lane (OAKE_BENCH_LANES=1: every kernel strictly after its predecessor, which is the condition
+# bench.py's own per-kernel stamps are taken under) — the rocprofv3 --kernel-trace --stats summary of the same
+# command and separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ); plus the two-lane kernel stats for the record.
+# All RAW tool output, under gpurun_out/<tag>/<mode>/, with a session stamp every derived number carries.
+# usage: bash tools/profile_round.sh [tag=r04] [modes="globals blocks objects"] [tests=1]
+# In the container afterwards:  python tools/collect_profiles.py <tag> && python tools/derive_counters.py <tag>
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 MODES=${2:-"globals blocks objects"}
+TESTS=${3:-1}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 SESSION="$(hostname)-$(date -u +%Y%m%dT%H%M%SZ)"
 { echo "session: $SESSION"; echo "head: $(cat .git/HEAD 2>/dev/null || echo n/a)"; rocm-smi --showproductname 2>/dev/null | grep -i -m2 "card series\|gfx" ; rocm-smi --showmaxpower --showpower 2>/dev/null | grep -i "power" ; } > $O/session.txt
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_gpu.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+if [ "$TESTS" = "1" ]; then
+  python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+fi
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"
 for M in $MODES; do
-  D=$O/$M; mkdir -p $D
+  D=$O/$M; mkdir -p $D/lane1 $D/lanes2
   B="python $GRAFT_REPO_ROOT/bench.py --mode $M"
   (cd $GRAFT_REPO_ROOT && $B > $D/bench.json 2> $D/bench.err)
+  (cd $GRAFT_REPO_ROOT && OAKE_BENCH_LANES=1 $B --no-cpu-baseline --no-modes > $D/lane1/bench.json 2> $D/lane1/bench.err)
   cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o bench -- $B --steps 10 --warmup 3 --no-cpu-baseline --no-modes > $D/bench_under_rocprof.json 2> $D/rocprof_stats.err
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-modes > /dev/null 2> $D/pmc_fetch.err
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-modes > /dev/null 2> $D/pmc_write.err
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $D/pmc_sq -o p -- $B --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-modes > /dev/null 2> $D/pmc_sq.err
+  Q="--no-cpu-baseline --no-modes"
+  OAKE_BENCH_LANES=1 OAKE_BENCH_SUSTAINED_S=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D/lane1/stats -o bench -- $B --steps 10 --warmup 3 $Q > $D/lane1/bench_under_rocprof.json 2> $D/lane1/rocprof_stats.err
+  OAKE_BENCH_LANES=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/lane1/pmc_fetch -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_fetch.err
+  OAKE_BENCH_LANES=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/lane1/pmc_write -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_write.err
+  OAKE_BENCH_LANES=1 rocprofv3 --pmc $SQ --output-format csv -d $D/lane1/pmc_sq -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_sq.err
+  OAKE_BENCH_SUSTAINED_S=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D/lanes2/stats -o bench -- $B --steps 10 --warmup 3 $Q > $D/lanes2/bench_under_rocprof.json 2> $D/lanes2/rocprof_stats.err
   # keep what is judged, drop the bulky per-dispatch traces
-  find $D -name "*kernel_trace.csv" -delete; find $D -name "*agent_info.csv" -delete
+  find $D/lanes2 -name "*kernel_trace.csv" -delete; find $D -name "*agent_info.csv" -delete  # (lane1's trace stays: per-dispatch durations)
   cd $GRAFT_REPO_ROOT
 done
 find $O -type f | xargs ls -la | awk '{print $5, $9}' | sort -n | tail -40
 cat $O/session.txt $O/pytest_gpu.txt $O/smoke.txt
 for M in $MODES; do tail -c 300 $O/$M/bench.json; echo; done
-# In the container afterwards:
-#   for M in globals blocks objects; do mkdir -p profiles/r02/$M; cp gpurun_out/r02/$M/bench.json gpurun_out/r02/$M/bench_under_rocprof.json profiles/r02/$M/;
-#     cp gpurun_out/r02/$M/stats/*/bench_kernel_stats.csv profiles/r02/$M/rocprofv3_kernel_stats.csv; ... (tools/collect_profiles.py)
