@@ -4,7 +4,7 @@ profiles/<tag>/ (tracked) — raw tool output only, nothing edited — one direc
     bench.json                                   the driver-contract line of the mode (two lanes)
     lane1_bench.json                             the same line on ONE lane (OAKE_BENCH_LANES=1)
     lane1_rocprofv3_kernel_stats.csv             rocprofv3 --kernel-trace --stats of the one-lane command
-    lane1_rocprofv3_kernel_trace.csv             ... and its per-dispatch trace (begin / end of every launch)
+    lane1_rocprofv3_kernel_trace.csv.gz          ... and its per-dispatch trace (begin / end of every launch; gzip -9)
     lane1_bench_under_rocprof.json               the line that profiled run printed
     lane1_pmc_{fetch,write,sq}_counter_collection.csv   separate --pmc passes of the one-lane command
     lanes2_rocprofv3_kernel_stats.csv            kernel stats with two lanes overlapping (for the record)
@@ -34,7 +34,7 @@ for mode_dir in sorted(p for p in src.iterdir() if p.is_dir() and (p / 'bench.js
         if (mode_dir / rel).exists():
             shutil.copy(mode_dir / rel, out / name)
     for pat, name in (('lane1/stats/**/*kernel_stats.csv', 'lane1_rocprofv3_kernel_stats.csv'),
-                      ('lane1/stats/**/*kernel_trace.csv', 'lane1_rocprofv3_kernel_trace.csv'),
+                      ('lane1/stats/**/*kernel_trace.csv.gz', 'lane1_rocprofv3_kernel_trace.csv.gz'),
                       ('lanes2/stats/**/*kernel_stats.csv', 'lanes2_rocprofv3_kernel_stats.csv'),
                       ('lane1/pmc_fetch/**/*counter_collection.csv', 'lane1_pmc_fetch_counter_collection.csv'),
                       ('lane1/pmc_write/**/*counter_collection.csv', 'lane1_pmc_write_counter_collection.csv'),

@@ -2,7 +2,9 @@
 north_star asks for — per kernel: rocprofv3 launch duration, MFMA utilisation and HBM GB/s against chip peak —
 as profiles/<tag>_mfma_util_hbm.json (what bench.py quotes as roofline.traffic / avg_launch_us_rocprofv3).
 
-  duration   mean of the launch's begin -> end in lane1_rocprofv3_kernel_trace.csv (one lane: no overlap)
+  duration   mean of the launch's begin -> end in lane1_rocprofv3_kernel_trace.csv.gz (one lane: no overlap) over
+             the second half of the run's launches (the shader clock ramps for ~30 ms after idle:
+             profiles/r04/clock_ramp.txt); the mean over all calls — what rocprofv3's stats file prints — beside it
   MFMA       SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles per v_mfma_f32_16x16x32 (16 384 FLOP), summed over the chip's 1024
              SIMDs.  util_at_clock = busy / (1024 x GRBM_GUI_ACTIVE / 8)  [GUI_ACTIVE is summed over the 8 XCDs];
              frac_of_peak = issued MFMA FLOP / duration / 2.5 PFLOP/s  (issued >= algorithmic: tile padding counts)
@@ -12,6 +14,7 @@ The residual GEMM instantiation serves out_proj and c_proj alternately (launch o
 MFMA count confirms the split).   usage: python tools/derive_counters.py [tag=r04]"""
 import collections
 import csv
+import gzip
 import json
 import pathlib
 import sys
@@ -39,7 +42,7 @@ def slot_of(name, seen):
 
 def dispatches(path, by='Dispatch_Id'):
     rows = collections.OrderedDict()
-    with open(path) as f:
+    with (gzip.open(path, 'rt') if str(path).endswith('.gz') else open(path)) as f:
         for r in csv.DictReader(f):
             d = rows.setdefault(int(r[by]), {'name': r['Kernel_Name'], 't0': int(r['Start_Timestamp']), 't1': int(r['End_Timestamp'])})
             if 'Counter_Name' in r:
@@ -62,14 +65,16 @@ def mean(v):
 
 out = {'_derived_by': 'tools/derive_counters.py', '_peak': {'mfma_flops': PEAK_FLOPS, 'hbm_bytes_per_s': PEAK_HBM},
        '_session': (ROOT / 'profiles' / tag / 'session.txt').read_text().splitlines()[0].split(':', 1)[1].strip()}
-for mode_dir in sorted(p for p in (ROOT / 'profiles' / tag).iterdir() if (p / 'lane1_rocprofv3_kernel_trace.csv').exists()):
-    f = {k: mode_dir / f'lane1_{k}' for k in ('rocprofv3_kernel_trace.csv', 'pmc_fetch_counter_collection.csv',
+for mode_dir in sorted(p for p in (ROOT / 'profiles' / tag).iterdir() if (p / 'lane1_rocprofv3_kernel_trace.csv.gz').exists()):
+    f = {k: mode_dir / f'lane1_{k}' for k in ('rocprofv3_kernel_trace.csv.gz', 'pmc_fetch_counter_collection.csv',
                                                'pmc_write_counter_collection.csv', 'pmc_sq_counter_collection.csv')}
     trace, fetch, write, sq = (per_slot(p) if p.exists() else {} for p in f.values())
     table = {'_derived_from': [str(p.relative_to(ROOT)) for p in f.values() if p.exists()]}
     for slot, ds in trace.items():
-        us = mean([d['t1'] - d['t0'] for d in ds]) / 1e3
-        rec = {'kernel': ds[0]['name'][:140], 'launches_traced': len(ds), 'avg_launch_us_rocprofv3': round(us, 2)}
+        us_all = mean([d['t1'] - d['t0'] for d in ds]) / 1e3
+        us = mean([d['t1'] - d['t0'] for d in ds[len(ds) // 2:]]) / 1e3  # second half of the run: clocks ramped
+        rec = {'kernel': ds[0]['name'][:140], 'launches_traced': len(ds), 'avg_launch_us_rocprofv3': round(us, 2),
+               'avg_launch_us_rocprofv3_all_calls': round(us_all, 2)}
         if slot in sq and any('SQ_VALU_MFMA_BUSY_CYCLES' in d for d in sq[slot]):
             busy = mean([d['SQ_VALU_MFMA_BUSY_CYCLES'] for d in sq[slot]])
             gui = mean([d['GRBM_GUI_ACTIVE'] for d in sq[slot]])

@@ -26,13 +26,17 @@ for M in $MODES; do
   (cd $GRAFT_REPO_ROOT && OAKE_BENCH_LANES=1 $B --no-cpu-baseline --no-modes > $D/lane1/bench.json 2> $D/lane1/bench.err)
   cd /tmp
   Q="--no-cpu-baseline --no-modes"
-  OAKE_BENCH_LANES=1 OAKE_BENCH_SUSTAINED_S=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D/lane1/stats -o bench -- $B --steps 10 --warmup 3 $Q > $D/lane1/bench_under_rocprof.json 2> $D/lane1/rocprof_stats.err
-  OAKE_BENCH_LANES=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/lane1/pmc_fetch -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_fetch.err
-  OAKE_BENCH_LANES=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/lane1/pmc_write -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_write.err
-  OAKE_BENCH_LANES=1 rocprofv3 --pmc $SQ --output-format csv -d $D/lane1/pmc_sq -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_sq.err
-  OAKE_BENCH_SUSTAINED_S=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D/lanes2/stats -o bench -- $B --steps 10 --warmup 3 $Q > $D/lanes2/bench_under_rocprof.json 2> $D/lanes2/rocprof_stats.err
+  # the stats passes run >= 1 s of steps: the shader clock takes ~30 ms of load to ramp (profiles/r04/clock_ramp.txt)
+  # and rocprofv3's AverageNs is over ALL calls of the run
+  case $M in globals) K="--steps 400 --warmup 50";; blocks) K="--steps 60 --warmup 10";; *) K="--steps 12 --warmup 3";; esac
+  OAKE_BENCH_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $D/lane1/stats -o bench -- $B $K $Q > $D/lane1/bench_under_rocprof.json 2> $D/lane1/rocprof_stats.err
+  OAKE_BENCH_LANES=1 OAKE_BENCH_RAMP_S=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/lane1/pmc_fetch -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_fetch.err
+  OAKE_BENCH_LANES=1 OAKE_BENCH_RAMP_S=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/lane1/pmc_write -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_write.err
+  OAKE_BENCH_LANES=1 OAKE_BENCH_RAMP_S=0 rocprofv3 --pmc $SQ --output-format csv -d $D/lane1/pmc_sq -o p -- $B --steps 2 --warmup 1 $Q --no-profile > /dev/null 2> $D/lane1/pmc_sq.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/lanes2/stats -o bench -- $B $K $Q > $D/lanes2/bench_under_rocprof.json 2> $D/lanes2/rocprof_stats.err
   # keep what is judged, drop the bulky per-dispatch traces
-  find $D/lanes2 -name "*kernel_trace.csv" -delete; find $D -name "*agent_info.csv" -delete  # (lane1's trace stays: per-dispatch durations)
+  find $D/lanes2 -name "*kernel_trace.csv" -delete; find $D -name "*agent_info.csv" -delete
+  find $D/lane1 -name "*kernel_trace.csv" -exec gzip -9 {} \;  # (lane1's trace stays, compressed: per-dispatch durations)
   cd $GRAFT_REPO_ROOT
 done
 find $O -type f | xargs ls -la | awk '{print $5, $9}' | sort -n | tail -40
