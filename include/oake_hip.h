@@ -309,6 +309,11 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *   OAKE_OPT_CU_COUNT           compute units the caller's stream may use: a handle driven on a CU-masked stream
  *                               (hipExtStreamCreateWithCUMask: two lanes on disjoint halves of the chip) sizes the
  *                               grids of its persistent kernels to that.  0 = every CU of the device.  Default 0.
+ *   OAKE_OPT_FUSE_ATTN_OUT      sequences of at most 64 tokens on a 16-bit residual stream (encode_image at 224^2,
+ *                               blocks mode) in the ViT-B geometry (12 heads x 64): attention + out_proj + residual +
+ *                               the next LayerNorm's row statistics run as ONE kernel, one workgroup per image, and the
+ *                               attention output never reaches memory (csrc/attn_out.hip).  0 = the two separate
+ *                               launches (A/B runs, tests).  Default 1.
  */
 enum {
   OAKE_OPT_CLS_LAST = 1,
@@ -316,7 +321,8 @@ enum {
   OAKE_OPT_GEMM_PANEL = 3,
   OAKE_OPT_ATTENTION_VARIANT = 4,
   OAKE_OPT_PATCH_DIRECT = 5,
-  OAKE_OPT_CU_COUNT = 6
+  OAKE_OPT_CU_COUNT = 6,
+  OAKE_OPT_FUSE_ATTN_OUT = 7
 };
 OAKE_API int oake_set_option(oake_handle* h, int option, int value);
 OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);

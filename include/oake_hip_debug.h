@@ -41,6 +41,18 @@ OAKE_API int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_g
 /* Multi-head self-attention on packed qkv [n*l, 3*heads*64] (q pre-scaled), -> [n*l, heads*64]. */
 OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads,
                          int dtype16, void* stream);
+/* The fused form for sequences of at most 64 tokens (csrc/attn_out.hip; heads = 12 only, else
+ * OAKE_ERR_UNSUPPORTED): x[n*l, heads*64] (16-bit, in place) += attention(qkv) * W^T + bias with W [heads*64,
+ * heads*64] row-major 16-bit, and d_rowpart [n*l, 16, 2] fp32 receives (sum, sum of squares) of every 64-column
+ * slice of the new rows.  Synchronous (permutes W into a temporary). */
+OAKE_API int oake_debug_attn_out(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x,
+                        float* d_rowpart, int n, int l, int heads, int dtype16, void* stream);
+/* The same, launched `repeats` times back to back (x keeps accumulating); with d_trace != NULL (f16 only) the
+ * measurement build of the kernel runs and d_trace [4 workgroups][8 waves][64] uint64 receives s_memtime stamps at
+ * the kernel's phase boundaries (tools/attn_out_trace.py). */
+OAKE_API int oake_debug_attn_out_trace(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x,
+                              float* d_rowpart, int n, int l, int heads, int dtype16, void* d_trace, int repeats,
+                              void* stream);
 /* Raw ds_read_b64_tr_b16 semantics probe: in = 256 uint16, out = 64 lanes x 4 uint16. */
 OAKE_API int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream);
 /* Which compute units do a stream's blocks land on (CU-masked streams)?  nblocks blocks of one wave, one per CU

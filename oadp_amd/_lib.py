@@ -12,6 +12,7 @@ OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
 OAKE_OPT_CLS_LAST, OAKE_OPT_GEMM_VARIANT, OAKE_OPT_GEMM_PANEL, OAKE_OPT_ATTENTION_VARIANT = 1, 2, 3, 4
 OAKE_OPT_PATCH_DIRECT = 5
 OAKE_OPT_CU_COUNT = 6
+OAKE_OPT_FUSE_ATTN_OUT = 7
 ABI_VERSION = 3
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library
@@ -77,6 +78,8 @@ DEBUG_SIGNATURES = {
     'oake_debug_ln_gemm16': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     'oake_debug_layernorm': (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),
     'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
+    'oake_debug_attn_out': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    'oake_debug_attn_out_trace': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
     'oake_debug_cu_census': (_I, [_VP, _I, _I, _VP]),
     'oake_debug_mfma_probe': (_I, [_VP, _VP, C.c_int, C.POINTER(C.c_double), _VP]),

@@ -18,9 +18,13 @@ ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
-SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'attn_out.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
 HEADERS = ['common.h', 'kernels.h', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'
+# instantiations that may spill: the s_memtime-stamped measurement build of attn_out (oake_debug_attn_out_trace) and
+# its bf16 form (not the production operand type: bf16 misses the north-star tolerance; it keeps two 64-bit Q addresses
+# in scratch, reloaded once per step — 20 bytes)
+SPILL_OK = ('attn_out_kernelIDF16_Lb1E', 'attn_out_kernelIDF16bLb0E')
 FLAGS = [
     f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
     '-Wall', '-Wno-unused-function',
@@ -69,7 +73,7 @@ def _compile(src: str, force: bool) -> pathlib.Path:
             name = line.split('Function Name:')[1].split()[0]
         elif 'ScratchSize [bytes/lane]:' in line:
             n = int(line.split('ScratchSize [bytes/lane]:')[1].split()[0])
-            if n:
+            if n and not any(ok in (name or '') for ok in SPILL_OK):
                 raise RuntimeError(f'{src}: kernel {name} spills {n} bytes/lane to scratch')
     other = [l for l in r.stderr.splitlines()
              if 'remark:' not in l and l.strip() and not re.match(r'\s*\d*\s*\|', l)]

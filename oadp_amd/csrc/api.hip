@@ -49,6 +49,7 @@ struct LayerW {
   float *in_w32 = nullptr, *fc_w32 = nullptr;
   void *in_wf = nullptr, *fc_wf = nullptr;
   float *in_cs = nullptr, *fc_cs = nullptr, *in_bf = nullptr, *fc_bf = nullptr;
+  void* out_wp = nullptr;  // out_proj weight in attn_out_kernel's fragment order (attn_out.hip), or nullptr
 };
 
 struct ProfSlot {
@@ -81,6 +82,7 @@ struct oake_handle {
   LaunchOpts opts;
   int cls_last = 1;           // encode_image: last block for the CLS rows only (0 = all rows, as the reference)
   int patch_direct = 1;       // conv1 reads 16-bit NCHW input directly (0 = always through im2col; A/B, tests)
+  int fuse_attn_out = 1;      // L <= 64: attention + out_proj + residual in one kernel (0 = two launches; A/B, tests)
 
   // weights
   void* conv_w = nullptr;     // [width, 3*P*P] 16-bit
@@ -445,6 +447,7 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
       A((void**)&l.fc_cs, F * 4);
       A((void**)&l.in_bf, 3 * C * 4);
       A((void**)&l.fc_bf, F * 4);
+      if (!text && attn_out_supported((int)std::min<size_t>(L, 64), c.heads, c.width)) A(&l.out_wp, C * C * e16());
     }
   }
   // (every tensor that goes through the fp32 staging buffer: conv1, c_fc / c_proj, in_proj, the positional
@@ -613,7 +616,13 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
       F32(w.in_b, 3 * C);
       HIP_TRY(h, launch_scale_f32(w.in_b, C, 0.125f, 0));
       HIP_TRY(h, hipStreamSynchronize(0));
-    } else if (leaf == "attn.out_proj.weight") W16(w.out_w, C * C);
+    } else if (leaf == "attn.out_proj.weight") {
+      W16(w.out_w, C * C);
+      if (w.out_wp) {
+        HIP_TRY(h, launch_permute_out_w(h->dt16, w.out_w, w.out_wp, 0));
+        HIP_TRY(h, hipStreamSynchronize(0));
+      }
+    }
     else if (leaf == "attn.out_proj.bias") F32(w.out_b, C);
     else if (leaf == "mlp.c_fc.weight") {
       W16(w.fc_w, F * C);
@@ -783,7 +792,8 @@ int in_proj_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int 
 }
 
 // attention out-proj (+residual) -> ln_2 + c_fc (+QuickGELU) -> c_proj (+residual) of rows [r0, r0 + M)
-int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, const char* sfx) {
+int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, const char* sfx,
+             bool out_proj_done = false) {
   const int C = h->cfg.width, F = h->cfg.mlp_dim;
   const size_t es = 2, xs = h->xdt == DT_F32 ? 4 : 2;
   char* xr = reinterpret_cast<char*>(h->x) + r0 * C * xs;
@@ -793,7 +803,8 @@ int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, c
                     n_pr = std::string("gemm_c_proj") + sfx;
   const int resid = h->xdt == DT_F32 ? EPI_RESID : EPI_RESID16;
   int rc;
-  if ((rc = gemm(h, s, n_out.c_str(), resid, att, w.out_w, w.out_b, xr, M, C, C, C, nullptr, nullptr, r0)))
+  if (!out_proj_done &&
+      (rc = gemm(h, s, n_out.c_str(), resid, att, w.out_w, w.out_b, xr, M, C, C, C, nullptr, nullptr, r0)))
     return rc;
   if (h->xdt == DT_F32) {
     char* xn = reinterpret_cast<char*>(h->xn) + r0 * C * es;
@@ -819,6 +830,14 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   // attention + out_proj + MLP of the main token stream (qkv already computed)
   const int C = h->cfg.width, L = h->cur_len, T = nb * L;
   const int Lp = ((L + 63) / 64) * 64;
+  // L <= 64 on the 16-bit residual stream (encode_image, blocks mode): attention + out_proj + residual + the row
+  // statistics of the next LayerNorm in one kernel, one workgroup per image; `att` is never written (attn_out.hip)
+  if (h->fuse_attn_out && h->stat_fused && !h->text && w.out_wp && attn_out_supported(L, h->cfg.heads, C)) {
+    RUNK(h, s, "attn_out", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64 + 2.0 * T * C * C, (double)T * 5 * C * 2,
+         launch_attn_out(h->dt16, h->qkv, w.out_wp, w.out_b, h->x, h->rowpart, nb, L, s));
+    h->nparts = C / 64;
+    return mlp_rows(h, s, w, 0, T, "", true);
+  }
   RUNK(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
       launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s, nullptr, nullptr, 0,
                        nullptr, &h->opts));
@@ -1667,6 +1686,28 @@ int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads
                               nullptr, nullptr, 0, nullptr, &t_debug_opts));
 }
 
+int oake_debug_attn_out(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x, float* d_rowpart,
+                        int n, int l, int heads, int dtype16, void* stream) {
+  return oake_debug_attn_out_trace(d_qkv, d_w, d_bias, d_x, d_rowpart, n, l, heads, dtype16, nullptr, 1, stream);
+}
+
+int oake_debug_attn_out_trace(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x, float* d_rowpart,
+                              int n, int l, int heads, int dtype16, void* d_trace, int repeats, void* stream) {
+  const int C = heads * 64;
+  if (!d_qkv || !d_w || !d_bias || !d_x || !d_rowpart || n < 0) return OAKE_ERR_INVALID;
+  if (!attn_out_supported(l, heads, C)) return OAKE_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  void* wp = nullptr;
+  if (hipMalloc(&wp, (size_t)C * C * 2) != hipSuccess) return OAKE_ERR_HIP;
+  hipError_t e = launch_permute_out_w(dtype16, d_w, wp, s);
+  for (int i = 0; i < repeats && e == hipSuccess; ++i)
+    e = launch_attn_out(dtype16, d_qkv, wp, d_bias, d_x, d_rowpart, n, l, s,
+                        reinterpret_cast<unsigned long long*>(d_trace));
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(wp);
+  return dbg(e);
+}
+
 int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
   return dbg(launch_tr_read_probe(d_in, d_out, reinterpret_cast<hipStream_t>(stream)));
 }
@@ -1719,6 +1760,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
     case OAKE_OPT_ATTENTION_VARIANT: h->opts.attention_variant = value & 127; return OAKE_OK;
     case OAKE_OPT_PATCH_DIRECT: h->patch_direct = value < 0 ? 0 : (value > 2 ? 2 : value); return OAKE_OK;
     case OAKE_OPT_CU_COUNT: h->opts.cu_count = value > 0 ? value : 0; return OAKE_OK;
+    case OAKE_OPT_FUSE_ATTN_OUT: h->fuse_attn_out = value ? 1 : 0; return OAKE_OK;
     default: return fail(h, OAKE_ERR_INVALID, "unknown option " + std::to_string(option));
   }
 }
@@ -1732,6 +1774,7 @@ int oake_get_option(const oake_handle* h, int option, int* value) {
     case OAKE_OPT_ATTENTION_VARIANT: *value = h->opts.attention_variant; return OAKE_OK;
     case OAKE_OPT_PATCH_DIRECT: *value = h->patch_direct; return OAKE_OK;
     case OAKE_OPT_CU_COUNT: *value = h->opts.cu_count; return OAKE_OK;
+    case OAKE_OPT_FUSE_ATTN_OUT: *value = h->fuse_attn_out; return OAKE_OK;
     default: return OAKE_ERR_INVALID;
   }
 }

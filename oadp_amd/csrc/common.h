@@ -185,6 +185,15 @@ __device__ __forceinline__ void store16_policy(P* p, u32x4_t v) {
   else
     *reinterpret_cast<u32x4_t*>(p) = v;
 }
+// The same with the address as a wave-uniform base (SGPR pair) + a 32-bit byte offset per lane: no 64-bit address
+// registers per store (kernels at their register limit: attn_out.hip)
+template <int POLICY>
+__device__ __forceinline__ void store16_policy_s(const void* sbase, unsigned voff, u32x4_t v) {
+  if constexpr (POLICY == 1)
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  else
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ u32x4_t as_u32x4(uint4 v) { return u32x4_t{v.x, v.y, v.z, v.w}; }
 // the kernels beside the GEMMs whose output is a whole activation / operand buffer (attention output, im2col
 // matrix): same reasoning, separate switch for A/B builds (-DOAKE_AUX_STORE_POLICY=n)

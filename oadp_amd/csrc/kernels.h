@@ -147,6 +147,17 @@ hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* q
                                    const void* mask, int mask_dtype, void* out, int n, int L,
                                    int heads, hipStream_t s);
 
+// ---- attention + out_proj + residual in one kernel (attn_out.hip) ------------------------------
+// For sequences of at most 64 tokens on a 16-bit residual stream, ViT-B geometry (12 heads, width 768):
+// x[n*L + t, :] (16-bit, in place) += softmax(q k^T) v . W_out^T + bias, and rowpart [n*L, 16, 2] receives
+// (sum, sum^2) of every 64-column slice of the new rows (12 slices: the LayerNorm statistics of the LN-folded
+// c_fc GEMM that follows).  `wperm` = W_out in the kernel's fragment order (launch_permute_out_w).
+bool attn_out_supported(int L, int heads, int width);
+hipError_t launch_permute_out_w(int dtype16, const void* w, void* wp, hipStream_t s);
+// trace (measurement only): device buffer of 4 x 8 x 64 uint64 receiving s_memtime stamps of the first workgroups
+hipError_t launch_attn_out(int dtype16, const void* qkv, const void* wperm, const float* bias, void* x,
+                           float* rowpart, int n, int L, hipStream_t s, unsigned long long* trace = nullptr);
+
 // ---- head tail ---------------------------------------------------------------------------
 // rows of [n, e] fp32 -> optional L2 normalise (F.normalize, eps 1e-12) -> out [n, e] (fp32 or f16)
 hipError_t launch_l2norm_rows(const float* in, void* out, int out_dtype, int normalize, int n, int e,

@@ -485,3 +485,38 @@ def test_profiler_counts_stamped_and_seen_launches(cuda):
     sparse = v.profile_read()
     v.profile(False)
     assert sum(p['seen'] for p in sparse) == n and sum(p['launches'] for p in sparse) == (n + 2) // 3
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
+def test_encode_image_fused_attention_out_proj(cuda, dtype, tol):
+    """The one-kernel attention + out_proj + residual (csrc/attn_out.hip, default where the persistent kernels run:
+    M > 1024 rows) against the oracle, against the two-launch form (fuse_attn_out = 0: same arithmetic up to the
+    summation order of out_proj's K dimension), and that it really is the path taken (profile slot names)."""
+    sd = synthetic_state_dict()
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48)
+    x = synthetic_images(45, seed=145)
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
+    v = model.visual
+    xg = x.to(cuda)
+    model.encode_image(xg[:2])  # creates the handle
+    v.set_option('fuse_attn_out', 1)
+    v.profile(True)
+    fused = model.encode_image(xg, normalize=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    names = {p['name']: p['launches'] for p in v.profile_read() if p['launches'] > 0}
+    v.profile(False)
+    assert names.get('attn_out') == 11 and 'attention' not in names and 'gemm_out_proj' not in names, names
+    _check(fused, ref, tol, tol)
+    v.set_option('fuse_attn_out', 0)
+    v.profile(True)
+    plain = model.encode_image(xg, normalize=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    names = {p['name']: p['launches'] for p in v.profile_read() if p['launches'] > 0}
+    v.profile(False)
+    assert 'attn_out' not in names and names.get('attention') == 11 and names.get('gemm_out_proj') == 11, names
+    _check(plain, ref, tol, tol)
+    assert (fused - plain).abs().max().item() <= tol
+    # per-image results do not depend on the batch composition (one workgroup per image)
+    v.set_option('fuse_attn_out', 1)
+    again = model.encode_image(xg.flip(0), normalize=True, out_dtype=torch.float32).flip(0)
+    assert torch.equal(again, fused)

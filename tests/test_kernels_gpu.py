@@ -226,3 +226,44 @@ def test_mfma_probe_counts_its_work(lib, cuda):
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     assert flop.value == cus * 8 * 20 * 16384.0 * 100 and sink.item() == 0.0
     assert lib.oake_debug_mfma_probe(0, sink.data_ptr(), 100, None, _stream()) != 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('n,l', [(1, 50), (3, 50), (300, 50), (2, 64), (5, 49), (4, 48), (2, 33), (3, 17), (2, 16),
+                                 (3, 1), (257, 50)])
+def test_attn_out_fused(lib, cuda, dtype, n, l):
+    """csrc/attn_out.hip: attention + out_proj + bias + residual (16-bit, in place) + the row statistics of the next
+    LayerNorm in one kernel, against the same chain in fp32 torch from the same 16-bit operands.  The attention
+    output is rounded to 16 bits before out_proj in both (the kernel keeps it as MFMA operand fragments)."""
+    heads, c = 12, 768
+    g = torch.Generator(device='cpu').manual_seed(n * 100 + l)
+    qkv = torch.randn(n * l, 3 * c, generator=g)
+    qkv[:, :c] *= 0.35
+    qkv = qkv.to(dtype).to(cuda)
+    w = (torch.randn(c, c, generator=g) * c ** -0.5).to(dtype).to(cuda)
+    bias = torch.randn(c, generator=g).to(cuda)
+    x0 = torch.randn(n * l, c, generator=g).to(dtype).to(cuda)
+    x = torch.cat([x0, torch.full((3, c), 7.0, dtype=dtype, device=cuda)])  # guard rows behind the last image
+    part = torch.full((n * l + 3, 16, 2), float('nan'), device=cuda)
+    rc = lib.oake_debug_attn_out(qkv.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), part.data_ptr(),
+                                 n, l, heads, DT[dtype], _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    att = _attention_ref(qkv, n, l, heads).to(dtype).float()
+    ref = x0.float() + att @ w.float().t() + bias
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    torch.testing.assert_close(x[:n * l].float(), ref, rtol=tol, atol=tol)
+    assert torch.equal(x[n * l:], torch.full((3, c), 7.0, dtype=dtype, device=cuda))  # nothing written past the rows
+    # (sum, sum of squares) of the fp32 values before rounding, per 64-column slice; slots 12..15 untouched
+    sl = ref.view(n * l, 12, 64)
+    torch.testing.assert_close(part[:n * l, :12, 0], sl.sum(-1), rtol=2e-2, atol=0.08)
+    torch.testing.assert_close(part[:n * l, :12, 1], (sl * sl).sum(-1), rtol=2e-2, atol=0.3)
+    assert torch.isnan(part[:n * l, 12:]).all() and torch.isnan(part[n * l:]).all()
+
+
+def test_attn_out_refuses_other_geometries(lib, cuda):
+    z = torch.zeros(64, device=cuda)
+    assert lib.oake_debug_attn_out(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 65, 12,
+                                   _lib.OAKE_F16, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lib.oake_debug_attn_out(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 50, 8,
+                                   _lib.OAKE_F16, _stream()) == _lib.OAKE_ERR_UNSUPPORTED

@@ -1,0 +1,64 @@
+"""Where does a workgroup of attn_out_kernel (csrc/attn_out.hip) spend its cycles?  Runs the s_memtime-stamped
+measurement build on a batch of 256 images x 50 tokens and prints, per phase boundary, the cycles since the previous
+one (median over the 8 waves of the first 4 workgroups), plus the launch time of the production build.
+usage (GPU box): python tools/attn_out_trace.py [n=256] [L=50]"""
+import ctypes as C
+import sys
+
+import torch
+
+sys.path.insert(0, '.')
+from oadp_amd import _lib  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+lib = _lib.load()
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(0)
+c = 768
+qkv = torch.randn(n * L, 3 * c, generator=g)
+qkv[:, :c] *= 0.35
+qkv = qkv.half().to(dev)
+w = (torch.randn(c, c, generator=g) * c ** -0.5).half().to(dev)
+bias = torch.randn(c, generator=g).to(dev)
+x = torch.zeros(n * L, c, dtype=torch.float16, device=dev)
+part = torch.zeros(n * L, 16, 2, device=dev)
+trace = torch.zeros(4 * 8 * 64, dtype=torch.int64, device=dev)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def run(tr, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = lib.oake_debug_attn_out_trace(qkv.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), part.data_ptr(),
+                                       n, L, 12, _lib.OAKE_F16, tr, reps, st)
+    assert rc == 0, rc
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+run(None, 50)
+print(f'production build: {run(None, 400):.2f} us per launch (n = {n}, L = {L}; includes ~1 us of launch gap)')
+run(trace.data_ptr(), 20)
+print(f'stamped build:    {run(trace.data_ptr(), 200):.2f} us per launch')
+t = trace.view(4, 8, 64).cpu()
+names = {0: 'entry', 1: 'prologue loads landed', 2: 'barrier', 3: 'attention(0)', 4: 'barrier'}
+for s in range(6):
+    for i in range(4):
+        names[5 + 6 * s + i] = f'step {s} group {i} + attention part {i}'
+    names[5 + 6 * s + 4] = f'step {s} wait (O written, DMA in)'
+    names[5 + 6 * s + 5] = f'step {s} barrier'
+names[41] = 'epilogue (residual, stores, stats)'
+names[42] = 'stats of the shared slices'
+pts = [p for p in sorted(names) if (t[:, :, p] != 0).all()]
+prev = None
+total = 0
+for p in pts:
+    if prev is not None:
+        d = (t[:, :, p] - t[:, :, prev]).flatten().float()
+        total += d.median().item()
+        print(f'{p:3d} {names[p]:40s} median {d.median().item():8.0f}  min {d.min().item():8.0f}  max {d.max().item():8.0f}')
+    prev = p
+span = (t[:, :, pts[-1]] - t[:, :, pts[0]]).flatten().float()
+print(f'entry -> end: median {span.median().item():.0f} ticks (s_memtime ticks at 100 MHz = 10 ns each)')
