@@ -789,6 +789,9 @@ def main() -> int:
     dist = world > 1
     td = None
     backend = os.environ.get('OAKE_BENCH_BACKEND', 'nccl')  # nccl IS RCCL on ROCm; gloo: two ranks may share a GPU
+    if world > 1:  # a rank of a multi-rank node keeps its share of the host's cores (OAKE_CPU_AFFINITY=0: off)
+        from oadp_amd.store import pin_cpus
+        pin_cpus()
     if DRY_PLUMBING:
         dev, backend = torch.device('cpu'), 'gloo'
     else:

@@ -25,7 +25,7 @@ import torch.utils.data
 import torch.utils.data.distributed
 
 from ..config import Config, parse_override
-from ..store import Store, get_local_rank, get_rank, get_world_size
+from ..store import Store, get_local_rank, get_rank, get_world_size, parse_shard, pin_cpus, shard_device_index
 from . import fastsave
 
 
@@ -406,12 +406,11 @@ class BaseValidator(ABC, Generic[T]):
         # OAKE_SHARD=r/W: the DistributedSampler shard r of W without a process group — array-job style
         # launches (one independent process per GPU or per node, nothing to rendezvous: the path has no
         # data-path collective), and measuring one rank's share of a W-rank sweep on a single GPU
-        if os.environ.get('OAKE_SHARD'):
+        shard = parse_shard()
+        if shard is not None:
             if world > 1:
                 raise RuntimeError('OAKE_SHARD and a torch.distributed launch (WORLD_SIZE > 1) are exclusive')
-            rank, world = (int(v) for v in os.environ['OAKE_SHARD'].split('/'))
-            if not 0 <= rank < world:
-                raise ValueError(f'OAKE_SHARD={os.environ["OAKE_SHARD"]}: need 0 <= r < W')
+            rank, world = shard
         if world > 1:
             config['sampler'] = torch.utils.data.distributed.DistributedSampler(
                 config['dataset'], num_replicas=world, rank=rank, shuffle=False)
@@ -625,8 +624,10 @@ class BaseValidator(ABC, Generic[T]):
             config.override(override)
 
         distributed = get_world_size() > 1
+        pin_cpus()  # a rank of a multi-rank node keeps its share of the host's cores (OAKE_CPU_AFFINITY=0: off)
         if Store.CUDA:
-            torch.cuda.set_device(get_local_rank() % torch.cuda.device_count())
+            # LOCAL_RANK under a launcher; shard r of OAKE_SHARD=r/W without one
+            torch.cuda.set_device(shard_device_index(torch.cuda.device_count()))
         if distributed:
             backend = pick_backend(Store.CUDA, torch.cuda.device_count() if Store.CUDA else 0)
             torch.distributed.init_process_group(backend=backend)
@@ -652,8 +653,9 @@ class BaseValidator(ABC, Generic[T]):
                 images = sum(r[0] for r in per_rank)
                 crops = sum(r[1] for r in per_rank)
                 secs = max(r[2] for r in per_rank)
+                shard = parse_shard()
+                who = f'shard {shard[0]} of {shard[1]} (OAKE_SHARD)' if shard else f'{len(per_rank)} rank(s)'
                 print(f'[{args.name}] {split_name}: {int(images)} images, {int(crops)} crops, '
-                      f'{secs:.1f} s, {images / max(secs, 1e-9):.1f} images/s over '
-                      f'{len(per_rank)} rank(s)', flush=True)
+                      f'{secs:.1f} s, {images / max(secs, 1e-9):.1f} images/s over {who}', flush=True)
         if distributed:
             torch.distributed.destroy_process_group()

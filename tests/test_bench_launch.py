@@ -87,3 +87,14 @@ def test_two_validator_ranks_share_one_gpu(tmp_path):
     assert len(line) == 1 and ' 2 rank(s)' in line[0] and ': 48 images, 1296 crops' in line[0], r.stdout[-2000:]
     files = sorted(p.name for p in (root / 'out_blocks_2').glob('*.pth'))
     assert files == [f'{i:012d}.pth' for i in range(48)]
+
+
+def test_gpus_8_plumbing_eight_gloo_ranks():
+    """BASELINE.json configs[3] / [4] launch shape without an 8-GPU node: `--gpus 8` re-executes under
+    torch.distributed.run with eight ranks; rendezvous, the all_reduce that counts the ranks, barrier,
+    max-over-ranks time and the 8 x 32-byte counters gather all run (gloo, no GPU work), ONE JSON line comes out."""
+    line = _run(['--gpus', '8', '--steps', '2', '--warmup', '1', '--no-profile'],
+                dict(OAKE_BENCH_DRY_PLUMBING='1'), timeout=900)
+    assert line['n_gpus'] == 8 and line['steps'] == 2 and line['scaling'] == 'weak'
+    assert 'images x8' in line['config']['sharding'] and 'ranks gathered: 8' in line['config']['sharding']
+    assert line['value'] is None and line['cpu_baseline'] is None

@@ -408,3 +408,94 @@ def test_pillow_release_guard_warns_once(recwarn):
     assert pp.check_pillow_version('9.5.0') is False and pp.check_pillow_version('9.5.0') is False
     hits = [w for w in recwarn.list if 'pinned bit-exactly' in str(w.message)]
     assert len(hits) == 1
+
+
+def _tree64(tmp_path):
+    return _synth.make_coco(tmp_path / 'coco64', [(64 + 4 * (i % 5), 60 + 3 * (i % 7)) for i in range(64)])
+
+
+def test_eight_validator_shards_cover_a_tree_exactly_once(tmp_path, monkeypatch):
+    """8-rank readiness without an 8-GPU node: OAKE_SHARD=r/8, r = 0..7, over a 64-image tree —
+    every image's file written by exactly one shard (DistributedSampler(shuffle=False): shard r takes sorted ids
+    r, r + 8, ...), the counters add up, the summary names the shard."""
+    coco = _tree64(tmp_path)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setenv('OAKE_CPU_AFFINITY', '0')
+    out = tmp_path / 'shards'
+    total, seen = 0, {}
+    for r in range(8):
+        monkeypatch.setenv('OAKE_SHARD', f'{r}/8')
+        v = globals_.Validator('g', _synth.OracleModel(), dataloader=_dl(coco, out), batch_size=4, device='cpu')
+        before = {p.name for p in out.glob('*.pth')} if out.exists() else set()
+        c = v.run()
+        new = {p.name for p in out.glob('*.pth')} - before
+        assert c.images == 8 and len(new) == 8
+        assert sorted(int(n[:-4]) for n in new) == coco['ids'][r::8]  # the sampler's arithmetic
+        for n in new:
+            assert n not in seen
+            seen[n] = r
+        total += c.images
+    assert total == 64 and sorted(seen) == [f'{i:012d}.pth' for i in coco['ids']]
+
+
+def test_eight_rank_gloo_validators(tmp_path):
+    """... and the same tree under a real 8-rank torch.distributed.run launch over gloo: disjoint files, all 64
+    images, one 8 x 32-byte counters gather, per-rank CPU pinning on (each rank reports the CPUs it kept)."""
+    coco = _tree64(tmp_path)
+    out = tmp_path / 'dist8'
+    script = tmp_path / 'run8.py'
+    script.write_text(f'''
+import os, sys, torch, torch.distributed as td
+sys.path.insert(0, {str(ROOT)!r}); sys.path.insert(0, {str(ROOT / "tests")!r})
+from tests import _synth
+from oadp_amd.config import Config
+from oadp_amd.oake import globals as g
+from oadp_amd.oake.base import gather_counters
+from oadp_amd.store import pin_cpus
+kept = pin_cpus()
+torch.set_num_threads(1)
+td.init_process_group('gloo')
+dl = Config(dataset=dict(root={coco["root"]!r}, annFile={coco["annFile"]!r}, output_dir={str(out)!r},
+            transform=_synth.preprocess()), num_workers=0)
+v = g.Validator('g', _synth.OracleModel(), dataloader=dl, batch_size=4, device='cpu')
+v.run()
+per_rank = gather_counters(v.counters, 'cpu')
+pins = [None] * td.get_world_size()
+td.all_gather_object(pins, (td.get_rank(), sorted(os.sched_getaffinity(0)), bool(kept)))
+if td.get_rank() == 0:
+    print('PINS', repr(pins), flush=True)
+    print('GATHER', len(per_rank), int(sum(r[0] for r in per_rank)), [int(r[0]) for r in per_rank], flush=True)
+td.destroy_process_group()
+''')
+    env = dict(os.environ, PYTHONPATH=str(ROOT))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'OAKE_SHARD', 'OAKE_CPU_AFFINITY'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8',
+                        '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'GATHER 8 64 [8, 8, 8, 8, 8, 8, 8, 8]' in r.stdout, r.stdout[-2000:]
+    assert sorted(int(p.stem) for p in out.iterdir()) == coco['ids']
+    pins = eval([ln for ln in r.stdout.splitlines() if ln.startswith('PINS ')][0][5:])
+    assert sorted(p[0] for p in pins) == list(range(8))
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) >= 8:  # every rank kept its own, disjoint share of this process's CPUs
+        assert all(kept for _, _, kept in pins), pins
+        assert sorted(c for _, cpus, _ in pins for c in cpus) == mine
+
+
+def test_shard_parsing_device_choice_and_cpu_slices():
+    from oadp_amd.store import cpu_slice, parse_shard, shard_device_index
+    assert parse_shard({}) is None and parse_shard({'OAKE_SHARD': '3/8'}) == (3, 8)
+    for bad in ('3', 'a/b', '8/8', '-1/4', '1/2/3'):
+        with pytest.raises(ValueError, match='OAKE_SHARD'):
+            parse_shard({'OAKE_SHARD': bad})
+    assert shard_device_index(8, {'OAKE_SHARD': '5/8'}) == 5      # eight shards on one node: eight GPUs
+    assert shard_device_index(1, {'OAKE_SHARD': '5/8'}) == 0      # HIP_VISIBLE_DEVICES narrowed to one device
+    assert shard_device_index(8, {'LOCAL_RANK': '2', 'OAKE_SHARD': '5/8'}) == 2
+    assert shard_device_index(8, {'LOCAL_RANK': '11'}) == 3       # more ranks than GPUs
+    assert shard_device_index(0, {}) == 0
+    cpus = list(range(256))
+    parts = [cpu_slice(i, 8, cpus) for i in range(8)]
+    assert all(len(p) == 32 for p in parts) and sorted(sum(parts, [])) == cpus
+    assert cpu_slice(2, 3, list(range(10))) == [6, 7, 8, 9] and cpu_slice(0, 16, list(range(8))) == list(range(8))

@@ -43,22 +43,34 @@ print(f'production build: {run(None, 400):.2f} us per launch (n = {n}, L = {L}; 
 run(trace.data_ptr(), 20)
 print(f'stamped build:    {run(trace.data_ptr(), 200):.2f} us per launch')
 t = trace.view(4, 8, 64).cpu()
-names = {0: 'entry', 1: 'prologue loads landed', 2: 'barrier', 3: 'attention(0)', 4: 'barrier'}
+ATT, OUT = [2, 3], [0, 1, 4, 5, 6, 7]  # wave ids by role (csrc/attn_out.hip)
+
+
+def report(title, waves, names):
+    print(title)
+    pts = [p for p in sorted(names) if (t[:, waves, p] != 0).all()]
+    prev = None
+    for p in pts:
+        if prev is not None:
+            d = (t[:, waves, p] - t[:, waves, prev]).flatten().float()
+            print(f'{p:3d} {names[p]:44s} median {d.median().item():8.0f}  min {d.min().item():8.0f}  max {d.max().item():8.0f}')
+        prev = p
+    span = (t[:, waves, pts[-1]] - t[:, waves, pts[0]]).flatten().float()
+    print(f'    entry -> last stamp: median {span.median().item():.0f} cycles (s_memtime counts shader-clock cycles here)')
+
+
+na = {0: 'entry'}
+for u in range(6):
+    na[1 + 8 * u] = f'unit {u}: Q / K / V rows landed'
+    na[2 + 8 * u] = f'unit {u}: scores (K Q^T, 4 query tiles)'
+    na[3 + 8 * u] = f'unit {u}: softmax'
+    na[4 + 8 * u] = f'unit {u}: P V + O fragments written'
+    na[5 + 8 * u] = f'unit {u}: barrier'
+report('attention waves', ATT, na)
+no = {0: 'entry', 1: 'first W fragments requested', 2: 'barrier (O of unit 0)'}
 for s in range(6):
     for i in range(4):
-        names[5 + 6 * s + i] = f'step {s} group {i} + attention part {i}'
-    names[5 + 6 * s + 4] = f'step {s} wait (O written, DMA in)'
-    names[5 + 6 * s + 5] = f'step {s} barrier'
-names[41] = 'epilogue (residual, stores, stats)'
-names[42] = 'stats of the shared slices'
-pts = [p for p in sorted(names) if (t[:, :, p] != 0).all()]
-prev = None
-total = 0
-for p in pts:
-    if prev is not None:
-        d = (t[:, :, p] - t[:, :, prev]).flatten().float()
-        total += d.median().item()
-        print(f'{p:3d} {names[p]:40s} median {d.median().item():8.0f}  min {d.min().item():8.0f}  max {d.max().item():8.0f}')
-    prev = p
-span = (t[:, :, pts[-1]] - t[:, :, pts[0]]).flatten().float()
-print(f'entry -> end: median {span.median().item():.0f} ticks (s_memtime ticks at 100 MHz = 10 ns each)')
+        no[3 + 5 * s + i] = f'step {s} group {i} (32 MFMAs)'
+    no[3 + 5 * s + 4] = f'step {s} barrier'
+no[40] = 'epilogue (residual, stores, stats)'
+report('out_proj waves', OUT, no)
