@@ -108,6 +108,16 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
     }
   };
   stamp(0);
+  // workgroup barrier WITHOUT __syncthreads' fence: the fence would wait for every request in flight — the attention
+  // waves' rows of the NEXT unit, the out_proj waves' W fragments — where only LDS traffic has to be ordered: an
+  // attention wave waits for its own ds_writes (lgkmcnt(0)) before it, an out_proj wave's reads of the previous
+  // step were consumed by its MFMAs
+#define OAKE_AO_BAR()                  \
+  do {                                 \
+    __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_barrier();      \
+    __builtin_amdgcn_sched_barrier(0); \
+  } while (0)
 
   if (wid == 2 || wid == 3) {
     // =================================== attention wave a: head 2 u + a of every step u ===========================
@@ -149,7 +159,29 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
       const char* qs = kvp(u) + a * 3 * kAoRegion;
       const char* ks = qs + kAoRegion;
       const char* vs = ks + kAoRegion;
+      // V fragments first (transposing reads; key enumeration of the score registers), BEFORE the next unit's rows are
+      // requested: hipcc cannot tell which LDS object ds_read_tr16_b64 reads and guards it with a wait for every
+      // LDS-DMA in flight (the plain ds_read_b128 of K and Q carry their variable's alias scope and are not guarded)
+      vec8 vf[4][2];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          const int row0 = 32 * ks2 + 4 * g + (fr >> 2);  // and row0 + 16: same swizzle
+          const int vsw = (row0 >> 1) & 7;
+          const int c4 = (fr & 3) * 4;
+          const char* p0 = vs + row0 * 128 + (((dt * 2 + (c4 >> 3)) ^ vsw) << 4) + (c4 & 4) * 2;
+          typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 16 * 128));
+          s16x8 both;
+          both[0] = lo[0]; both[1] = lo[1]; both[2] = lo[2]; both[3] = lo[3];
+          both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
+          vf[dt][ks2] = __builtin_bit_cast(vec8, both);
+        }
+      __builtin_amdgcn_sched_barrier(0);
       if (u + 1 < kAoSteps) dma_unit(u + 1);  // the next unit's rows, a whole step ahead
+      __builtin_amdgcn_sched_barrier(0);
       // S^T[key][query] = K Q^T for the four query tiles; the K fragments are read once and kept, Q streams through
       f32x4 sacc[4][4];
       {
@@ -184,8 +216,10 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float sc = sacc[q][kt][i];
-            sc = kt * 16 + 4 * g + i < L ? sc : -1e30f;  // padded keys
-            sacc[q][kt][i] = sc;
+            if (kt * 16 + 16 > L) {  // (uniform) a key tile with padded keys
+              sc = kt * 16 + 4 * g + i < L ? sc : -1e30f;
+              sacc[q][kt][i] = sc;
+            }
             mx = fmaxf(mx, sc);
           }
         mx = rows16_max(mx);
@@ -209,33 +243,16 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
         }
       }
       stamp(3 + 8 * u);
-      // O^T[d][query] = V^T P^T, V through the transposing read (key enumeration of the score registers); the V
-      // fragments are read once; the lane's accumulators = O[query fr][d = 16 dt + 4 g + j]: B fragments as they stand
+      // O^T[d][query] = V^T P^T; the lane's accumulators = O[query fr][d = 16 dt + 4 g + j]: B fragments as they stand
       char* ob = obp(u) + (a * 4 * 2) * 1024 + lane * 16;
       f32x4 oacc[4][4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        vec8 vf[2];
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-          const int row0 = 32 * ks2 + 4 * g + (fr >> 2);  // and row0 + 16: same swizzle
-          const int vsw = (row0 >> 1) & 7;
-          const int c4 = (fr & 3) * 4;
-          const char* p0 = vs + row0 * 128 + (((dt * 2 + (c4 >> 3)) ^ vsw) << 4) + (c4 & 4) * 2;
-          typedef s16x4 __attribute__((address_space(3))) * lds4_t;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 16 * 128));
-          s16x8 both;
-          both[0] = lo[0]; both[1] = lo[1]; both[2] = lo[2]; both[3] = lo[3];
-          both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
-          vf[ks2] = __builtin_bit_cast(vec8, both);
-        }
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 c = T16<T>::mfma(vf[0], pf[q][0], f32x4{0.f, 0.f, 0.f, 0.f});
-          oacc[q][dt] = T16<T>::mfma(vf[1], pf[q][1], c);
+          f32x4 c = T16<T>::mfma(vf[dt][0], pf[q][0], f32x4{0.f, 0.f, 0.f, 0.f});
+          oacc[q][dt] = T16<T>::mfma(vf[dt][1], pf[q][1], c);
         }
-      }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -247,7 +264,7 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
         }
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the fragments are written
       stamp(4 + 8 * u);
-      __syncthreads();                     // O of unit u complete (and the out_proj waves are done with unit u - 1)
+      OAKE_AO_BAR();                       // O of unit u complete (and the out_proj waves are done with unit u - 1)
       stamp(5 + 8 * u);
     }
     return;
@@ -292,7 +309,7 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
   };
   f32x4 acc[4][kAoNT];  // (first written by group 0's MFMAs)
   stamp(1);
-  __syncthreads();  // O of unit 0
+  OAKE_AO_BAR();  // O of unit 0
   stamp(2);
 #pragma unroll
   for (int s = 0; s < kAoSteps; ++s) {
@@ -314,10 +331,10 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
         else if (G + 1 == kAoGroups && (nt & 3) == 3) load_x(nt >> 2);  // the ring has drained: residual row tiles 0, 1
         __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks the loads to just before their use: no look-ahead)
       }
-      stamp(3 + 5 * s + i);
+      if (i == 3) stamp(3 + 5 * s + i);
     }
     if (s + 1 < kAoSteps) {
-      __syncthreads();  // O of unit s + 1
+      OAKE_AO_BAR();  // O of unit s + 1
       stamp(3 + 5 * s + 4);
     }
   }
@@ -376,6 +393,8 @@ void attn_out_kernel(const T* __restrict__ qkv, const T* __restrict__ wperm, con
   }
   stamp(40);
 }
+
+#undef OAKE_AO_BAR
 
 template <typename T, bool TRACE>
 hipError_t attn_out_launch_t(const void* qkv, const void* wperm, const float* bias, void* x, float* rowpart, int n,
