@@ -312,8 +312,10 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *   OAKE_OPT_FUSE_ATTN_OUT      sequences of at most 64 tokens on a 16-bit residual stream (encode_image at 224^2,
  *                               blocks mode) in the ViT-B geometry (12 heads x 64): attention + out_proj + residual +
  *                               the next LayerNorm's row statistics run as ONE kernel, one workgroup per image, and the
- *                               attention output never reaches memory (csrc/attn_out.hip).  0 = the two separate
- *                               launches (A/B runs, tests).  Default 1.
+ *                               attention output never reaches memory (csrc/attn_out.hip).  Parity-tested; measured
+ *                               slower than the two separate launches (39 vs 36 us per layer at batch 256: the
+ *                               out_proj weights stream through each CU's 64 B/clk vector-memory path once per
+ *                               image), so it is opt-in.  Default 0.
  */
 enum {
   OAKE_OPT_CLS_LAST = 1,

@@ -48,7 +48,7 @@ OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, 
 OAKE_API int oake_debug_attn_out(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x,
                         float* d_rowpart, int n, int l, int heads, int dtype16, void* stream);
 /* The same, launched `repeats` times back to back (x keeps accumulating); with d_trace != NULL (f16 only) the
- * measurement build of the kernel runs and d_trace [4 workgroups][8 waves][64] uint64 receives s_memtime stamps at
+ * measurement build of the kernel runs and d_trace [4 workgroups][12 waves][64] uint64 receives s_memtime stamps at
  * the kernel's phase boundaries (tools/attn_out_trace.py). */
 OAKE_API int oake_debug_attn_out_trace(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x,
                               float* d_rowpart, int n, int l, int heads, int dtype16, void* d_trace, int repeats,

@@ -82,7 +82,8 @@ struct oake_handle {
   LaunchOpts opts;
   int cls_last = 1;           // encode_image: last block for the CLS rows only (0 = all rows, as the reference)
   int patch_direct = 1;       // conv1 reads 16-bit NCHW input directly (0 = always through im2col; A/B, tests)
-  int fuse_attn_out = 1;      // L <= 64: attention + out_proj + residual in one kernel (0 = two launches; A/B, tests)
+  int fuse_attn_out = 0;      // L <= 64: attention + out_proj + residual in one kernel (csrc/attn_out.hip; measured
+                              // slower than the two launches — 39 vs 36 us per layer — so opt-in: tests, A/B runs)
 
   // weights
   void* conv_w = nullptr;     // [width, 3*P*P] 16-bit

@@ -154,7 +154,7 @@ hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* q
 // c_fc GEMM that follows).  `wperm` = W_out in the kernel's fragment order (launch_permute_out_w).
 bool attn_out_supported(int L, int heads, int width);
 hipError_t launch_permute_out_w(int dtype16, const void* w, void* wp, hipStream_t s);
-// trace (measurement only): device buffer of 4 x 8 x 64 uint64 receiving s_memtime stamps of the first workgroups
+// trace (measurement only): device buffer of 4 x 12 x 64 uint64 receiving s_memtime stamps of the first workgroups
 hipError_t launch_attn_out(int dtype16, const void* qkv, const void* wperm, const float* bias, void* x,
                            float* rowpart, int n, int L, hipStream_t s, unsigned long long* trace = nullptr);
 

@@ -23,7 +23,7 @@ w = (torch.randn(c, c, generator=g) * c ** -0.5).half().to(dev)
 bias = torch.randn(c, generator=g).to(dev)
 x = torch.zeros(n * L, c, dtype=torch.float16, device=dev)
 part = torch.zeros(n * L, 16, 2, device=dev)
-trace = torch.zeros(4 * 8 * 64, dtype=torch.int64, device=dev)
+trace = torch.zeros(4 * 12 * 64, dtype=torch.int64, device=dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -42,8 +42,8 @@ run(None, 50)
 print(f'production build: {run(None, 400):.2f} us per launch (n = {n}, L = {L}; includes ~1 us of launch gap)')
 run(trace.data_ptr(), 20)
 print(f'stamped build:    {run(trace.data_ptr(), 200):.2f} us per launch')
-t = trace.view(4, 8, 64).cpu()
-ATT, OUT = [2, 3], [0, 1, 4, 5, 6, 7]  # wave ids by role (csrc/attn_out.hip)
+t = trace.view(4, 12, 64).cpu()
+ATT, OUT = [8, 9, 10, 11], list(range(8))  # wave ids by role (csrc/attn_out.hip)
 
 
 def report(title, waves, names):
@@ -53,24 +53,24 @@ def report(title, waves, names):
     for p in pts:
         if prev is not None:
             d = (t[:, waves, p] - t[:, waves, prev]).flatten().float()
-            print(f'{p:3d} {names[p]:44s} median {d.median().item():8.0f}  min {d.min().item():8.0f}  max {d.max().item():8.0f}')
+            print(f'{p:3d} {names[p]:48s} median {d.median().item():8.0f}  min {d.min().item():8.0f}  max {d.max().item():8.0f}')
         prev = p
     span = (t[:, waves, pts[-1]] - t[:, waves, pts[0]]).flatten().float()
     print(f'    entry -> last stamp: median {span.median().item():.0f} cycles (s_memtime counts shader-clock cycles here)')
 
 
-na = {0: 'entry'}
+na = {0: 'entry', 1: 'rows of unit 0 requested and landed'}
 for u in range(6):
-    na[1 + 8 * u] = f'unit {u}: Q / K / V rows landed'
-    na[2 + 8 * u] = f'unit {u}: scores (K Q^T, 4 query tiles)'
-    na[3 + 8 * u] = f'unit {u}: softmax'
-    na[4 + 8 * u] = f'unit {u}: P V + O fragments written'
-    na[5 + 8 * u] = f'unit {u}: barrier'
+    na[2 + 8 * u] = f'unit {u}: barrier'
+    na[3 + 8 * u] = f'unit {u}: V reads, next rows requested, scores'
+    na[4 + 8 * u] = f'unit {u}: softmax (2 query tiles)'
+    na[5 + 8 * u] = f'unit {u}: P V + O fragments written'
+    na[6 + 8 * u] = f'unit {u}: wait (O written, next rows landed)'
 report('attention waves', ATT, na)
-no = {0: 'entry', 1: 'first W fragments requested', 2: 'barrier (O of unit 0)'}
-for s in range(6):
-    for i in range(4):
-        no[3 + 5 * s + i] = f'step {s} group {i} (32 MFMAs)'
-    no[3 + 5 * s + 4] = f'step {s} barrier'
+no = {0: 'entry', 1: 'first W fragments requested', 2: 'barriers (rows of unit 0; O of unit 0)'}
+for s_ in range(6):
+    no[3 + 2 * s_] = f'step {s_}: 4 groups x 24 MFMAs'
+    no[4 + 2 * s_] = f'step {s_}: barrier'
 no[40] = 'epilogue (residual, stores, stats)'
+no[41] = 'stats of the shared slices'
 report('out_proj waves', OUT, no)
