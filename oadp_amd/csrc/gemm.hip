@@ -99,6 +99,12 @@ struct TileMap {
 #ifndef OAKE_GEMM_A_AUX
 #define OAKE_GEMM_A_AUX 0
 #endif
+// ... and of the W operand's (round 4: with M slabs of 10 tile rows — OAKE_OPT_GEMM_PANEL = -10 — an XCD owns one A
+// slab (2.46 MB at K = 768) and streams every W panel past it exactly once; W fetched non-temporal should leave the
+// slab in the L2)
+#ifndef OAKE_GEMM_W_AUX
+#define OAKE_GEMM_W_AUX 0
+#endif
 #ifndef OAKE_STORE_POLICY_PARTIAL
 #define OAKE_STORE_POLICY_PARTIAL 0
 #endif
@@ -1095,7 +1101,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
                                                (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, OAKE_GEMM_A_AUX); \
             else                                                                             \
               __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                 \
-                                               (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0); \
+                                               (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, OAKE_GEMM_W_AUX); \
           }                                                                                  \
     }                                                                                        \
   } while (0)
