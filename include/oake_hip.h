@@ -297,15 +297,18 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               rows ln_post reads): K / V projections of all tokens, everything else of
  *                               that block for one row per image.  0 = run the block for every token as
  *                               the reference does (A/B runs, tests).  Default 1.
- *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default), 0..11 forced (csrc/gemm.hip)
+ *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default); forced: 0, 4, 5 in the production library, 0..11 in
+ *                               the lab build liboake_hip_lab.so (csrc/gemm.hip).  Other values: OAKE_ERR_INVALID.
  *   OAKE_OPT_GEMM_PANEL         GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside),
  *                               n < 0 = M slabs of -n tiles (column-major inside).  Default 0.
  *   OAKE_OPT_ATTENTION_VARIANT  bit set of attention kernel forms (documented with
- *                               oake_debug_set_attention_variant, oake_hip_debug.h).  Default 31.
+ *                               oake_debug_set_attention_variant, oake_hip_debug.h).  Default 31 — the only value the
+ *                               production library accepts (OAKE_ERR_INVALID otherwise); the lab build takes 0..127.
  *   OAKE_OPT_PATCH_DIRECT       conv1 gathers its patch rows straight from a 16-bit NCHW input batch (no
  *                               im2col pass) where the geometry allows it.  0 = always im2col.  2 = also from an
  *                               FP32 batch (patch 32): the GEMM's DMA waves load, round and write the LDS image
- *                               themselves (bit-identical; measured slower than im2col with two lanes).  Default 1.
+ *                               themselves (bit-identical; measured slower than im2col with two lanes: lab build only,
+ *                               the production library answers OAKE_ERR_INVALID).  Default 1.
  *   OAKE_OPT_CU_COUNT           compute units the caller's stream may use: a handle driven on a CU-masked stream
  *                               (hipExtStreamCreateWithCUMask: two lanes on disjoint halves of the chip) sizes the
  *                               grids of its persistent kernels to that.  0 = every CU of the device.  Default 0.

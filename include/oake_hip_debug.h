@@ -74,7 +74,11 @@ OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int ite
  * LDS up front with LDS-DMA and the key loop runs without barriers or global accesses (measured equal, so not
  * in the default either).  Default 31. */
 OAKE_API int oake_debug_set_attention_variant(int variant);
-/* GEMM configuration: -1 = automatic per shape, 0..11 = forced (see csrc/gemm.hip).
+/* 1 in liboake_hip_lab.so (built with -DOAKE_LAB=1: the production kernels plus every tile configuration, kernel form
+ * and measurement epilogue that lost its A/B), 0 in the production library, whose oake_debug_set_* / oake_set_option
+ * refuse the lab-only values (OAKE_ERR_UNSUPPORTED / OAKE_ERR_INVALID). */
+OAKE_API int oake_debug_lab_build(void);
+/* GEMM configuration: -1 = automatic per shape, 0..11 = forced (see csrc/gemm.hip; production build: -1, 0, 4, 5).
  * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel
  * entry points of the calling thread; a handle's own switches are set with oake_set_option. */
 OAKE_API int oake_debug_set_gemm_variant(int variant);

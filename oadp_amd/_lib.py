@@ -85,6 +85,7 @@ DEBUG_SIGNATURES = {
     'oake_debug_mfma_probe': (_I, [_VP, _VP, C.c_int, C.POINTER(C.c_double), _VP]),
     'oake_debug_set_attention_variant': (_I, [_I]),
     'oake_debug_set_gemm_variant': (_I, [_I]),
+    'oake_debug_lab_build': (_I, []),
     'oake_debug_gemm_resid16': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_set_gemm_panel': (_I, [_I]),
     'oake_debug_set_gemm_trace': (_I, [_VP]),
@@ -92,6 +93,8 @@ DEBUG_SIGNATURES = {
 }
 
 _lib = None
+_lab = None
+LAB_PATH = pathlib.Path(__file__).resolve().parent / 'liboake_hip_lab.so'
 
 
 class OakeTextConfig(C.Structure):
@@ -110,17 +113,34 @@ def load() -> C.CDLL:
         raise ImportError(
             f'{LIB_PATH} not found: build it with `python -m oadp_amd.build` '
             '(or __graft_entry__.build()); there is no CPU fallback')
-    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_LOCAL)
+    lib = _bind(C.CDLL(str(LIB_PATH), mode=C.RTLD_LOCAL), tolerate_missing_debug=bool(os.environ.get('OAKE_LIB')))
+    _lib = lib
+    return lib
+
+
+def _bind(lib: C.CDLL, tolerate_missing_debug: bool = False) -> C.CDLL:
     for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
-        if name in DEBUG_SIGNATURES and os.environ.get('OAKE_LIB') and not hasattr(lib, name):
+        if name in DEBUG_SIGNATURES and tolerate_missing_debug and not hasattr(lib, name):
             continue  # an older experiment build (tools/ab_env.py) may lack a newer debug entry point
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
     if lib.oake_abi_version() != ABI_VERSION:
-        raise ImportError(f'liboake_hip.so ABI {lib.oake_abi_version()} != {ABI_VERSION}')
-    _lib = lib
+        raise ImportError(f'{lib._name}: ABI {lib.oake_abi_version()} != {ABI_VERSION}')
     return lib
+
+
+def load_lab() -> C.CDLL:
+    """liboake_hip_lab.so: the production kernels plus the tile configurations / kernel forms / measurement
+    epilogues that lost their A/B (built with -DOAKE_LAB=1 by oadp_amd.build).  For tools/ and the variant tests
+    only — nothing in the product path loads it (pass ``lib=load_lab()`` to ``clip.load`` to drive a model on it)."""
+    global _lab
+    if _lab is None:
+        import torch  # noqa: F401
+        if not LAB_PATH.exists():
+            raise ImportError(f'{LAB_PATH} not found: build it with `python -m oadp_amd.build`')
+        _lab = _bind(C.CDLL(str(LAB_PATH), mode=C.RTLD_LOCAL))
+    return _lab
 
 
 class OakeError(RuntimeError):

@@ -55,14 +55,21 @@ def _digest(paths: list[pathlib.Path]) -> str:
     return h.hexdigest()
 
 
-def _compile(src: str, force: bool) -> pathlib.Path:
+LAB_LIB = ROOT / 'liboake_hip_lab.so'
+LAB_INCLUDES = ['gemm_lab_q4.inc', 'gemm_lab_duo.inc', 'attention_lab_full.inc']
+
+
+def _compile(src: str, force: bool, lab: bool = False) -> pathlib.Path:
     s = CSRC / src
-    obj = BUILD / (src + '.o')
-    stamp = BUILD / (src + '.sha')
-    dig = _digest([s] + [CSRC / hd for hd in HEADERS])
+    build = BUILD.parent / (BUILD.name + '_lab') if lab else BUILD
+    build.mkdir(parents=True, exist_ok=True)
+    obj = build / (src + '.o')
+    stamp = build / (src + '.sha')
+    extra = ['-DOAKE_LAB=1'] if lab else []
+    dig = _digest([s] + [CSRC / hd for hd in HEADERS] + ([CSRC / i for i in LAB_INCLUDES] if lab else [])) + str(lab)
     if not force and obj.exists() and stamp.exists() and stamp.read_text() == dig:
         return obj
-    cmd = [_hipcc(), *FLAGS, '-Rpass-analysis=kernel-resource-usage', '-c', str(s), '-o', str(obj)]
+    cmd = [_hipcc(), *FLAGS, *extra, '-Rpass-analysis=kernel-resource-usage', '-c', str(s), '-o', str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
@@ -78,25 +85,41 @@ def _compile(src: str, force: bool) -> pathlib.Path:
             if n > small and not any(ok in (name or '') for ok in SPILL_OK):
                 raise RuntimeError(f'{src}: kernel {name} spills {n} bytes/lane to scratch')
     other = [l for l in r.stderr.splitlines()
-             if 'remark:' not in l and l.strip() and not re.match(r'\s*\d*\s*\|', l)]
+             if 'remark:' not in l and l.strip() and not re.match(r'\s*\d*\s*\|', l)
+             and not l.startswith('In file included from')]
     if other:
         sys.stderr.write('\n'.join(other) + '\n')
     stamp.write_text(dig)
     return obj
 
 
-def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
-    BUILD.mkdir(parents=True, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+def _link(objs: list[pathlib.Path], lib: pathlib.Path, force: bool) -> None:
     newest = max(o.stat().st_mtime for o in objs)
-    if force or not LIB.exists() or LIB.stat().st_mtime < newest:
-        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', str(LIB), *map(str, objs)]
+    if force or not lib.exists() or lib.stat().st_mtime < newest:
+        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', str(lib), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+
+
+def build_library(force: bool = False, verbose: bool = False, lab: bool = True) -> pathlib.Path:
+    """liboake_hip.so — the product: the kernels pick_variant() / the default switches can select — and (lab=True)
+    liboake_hip_lab.so beside it: the same sources with -DOAKE_LAB=1, i.e. plus every tile configuration, kernel form
+    and measurement epilogue that lost its A/B; loaded only by tools/ and the variant tests (oadp_amd._lib.load_lab).
+    An OAKE_LIB_OUT experiment build is a single library with whatever OAKE_EXTRA_FLAGS say."""
+    BUILD.mkdir(parents=True, exist_ok=True)
+    jobs = [(src, False) for src in SOURCES]
+    if lab and not os.environ.get('OAKE_LIB_OUT'):
+        jobs += [(src, True) for src in SOURCES if src in ('gemm.hip', 'attention.hip', 'attn_out.hip', 'api.hip')]
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        objs = list(ex.map(lambda j: _compile(j[0], force, j[1]), jobs))
+    prod = objs[:len(SOURCES)]
+    _link(prod, LIB, force)
+    if len(objs) > len(SOURCES):
+        labobj = {j[0]: o for j, o in zip(jobs[len(SOURCES):], objs[len(SOURCES):])}
+        _link([labobj.get(src, po) for src, po in zip(SOURCES, prod)], LAB_LIB, force)
     if verbose:
-        print(f'built {LIB}')
+        print(f'built {LIB}' + (f' and {LAB_LIB.name}' if len(objs) > len(SOURCES) else ''))
     return LIB
 
 

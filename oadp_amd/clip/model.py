@@ -124,7 +124,7 @@ class VisionTransformer(_HookPoint):
 
     def __init__(self, state_dict: Mapping[str, torch.Tensor], *, compute_dtype=torch.float16,
                  residual_dtype: torch.dtype | None = None, max_batch: int = 256,
-                 device: int | None = None) -> None:
+                 device: int | None = None, lib=None) -> None:
         super().__init__()
         sd = {k: v.detach().to('cpu', torch.float32).contiguous()
               for k, v in state_dict.items() if k.startswith(VISION_PREFIX)}
@@ -149,7 +149,8 @@ class VisionTransformer(_HookPoint):
         self.residual_dtype = residual_dtype or compute_dtype
         self.max_batch = max_batch
         self.device = device
-        self._lib = _lib.load()
+        # (lib: the variant tests and tools pass the lab build, which also carries the experiments)
+        self._lib = lib if lib is not None else _lib.load()
         # Lanes: independent native handles (weights, activations and scratch each) so that consecutive
         # batches can run on different HIP streams and fill each other's kernel start-up and tail
         # (+10 % at batch 256, tools/two_stream_bench.py).  `lane` selects the handle every call on this

@@ -21,6 +21,9 @@
 #include <atomic>
 #include <vector>
 
+#ifndef OAKE_LAB
+#define OAKE_LAB 0  // 1: liboake_hip_lab.so (production kernels + the experiments that lost their A/B)
+#endif
 #include "../../include/oake_hip.h"
 #include "../../include/oake_hip_debug.h"
 #include "kernels.h"
@@ -1724,7 +1727,8 @@ int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, doubl
 }
 
 int oake_debug_set_gemm_variant(int variant) {
-  t_debug_opts.gemm_variant = variant < 0 ? -1 : variant;
+  if (variant < -1 || !gemm_variant_supported(variant)) return OAKE_ERR_UNSUPPORTED;
+  t_debug_opts.gemm_variant = variant;
   return OAKE_OK;
 }
 
@@ -1748,19 +1752,41 @@ int oake_debug_set_gemm_trace(void* d_trace) {
 }
 
 int oake_debug_set_attention_variant(int variant) {
-  t_debug_opts.attention_variant = variant & 127;
+  if (variant < 0 || variant > 127 || !attention_variant_supported(variant)) return OAKE_ERR_UNSUPPORTED;
+  t_debug_opts.attention_variant = variant;
   return OAKE_OK;
 }
+
+int oake_debug_lab_build(void) { return OAKE_LAB; }
 
 int oake_set_option(oake_handle* h, int option, int value) {
   if (!h) return OAKE_ERR_INVALID;
   switch (option) {
     case OAKE_OPT_CLS_LAST: h->cls_last = value ? 1 : 0; return OAKE_OK;
-    case OAKE_OPT_GEMM_VARIANT: h->opts.gemm_variant = value < 0 ? -1 : value; return OAKE_OK;
-    case OAKE_OPT_GEMM_PANEL: h->opts.gemm_panel = value; return OAKE_OK;
-    case OAKE_OPT_ATTENTION_VARIANT: h->opts.attention_variant = value & 127; return OAKE_OK;
-    case OAKE_OPT_PATCH_DIRECT: h->patch_direct = value < 0 ? 0 : (value > 2 ? 2 : value); return OAKE_OK;
-    case OAKE_OPT_CU_COUNT: h->opts.cu_count = value > 0 ? value : 0; return OAKE_OK;
+    case OAKE_OPT_GEMM_VARIANT:
+      if (value < -1 || !gemm_variant_supported(value))
+        return fail(h, OAKE_ERR_INVALID, "gemm variant " + std::to_string(value) + " is not in this build (production: -1, 0, 4, 5; "
+                    "the experiments live in liboake_hip_lab.so)");
+      h->opts.gemm_variant = value;
+      return OAKE_OK;
+    case OAKE_OPT_GEMM_PANEL:
+      if (value < -64 || value > 64) return fail(h, OAKE_ERR_INVALID, "gemm_panel must be in -64 .. 64");
+      h->opts.gemm_panel = value;
+      return OAKE_OK;
+    case OAKE_OPT_ATTENTION_VARIANT:
+      if (value < 0 || value > 127 || !attention_variant_supported(value))
+        return fail(h, OAKE_ERR_INVALID, "attention variant " + std::to_string(value) + " is not in this build (production: 31)");
+      h->opts.attention_variant = value;
+      return OAKE_OK;
+    case OAKE_OPT_PATCH_DIRECT:
+      if (value < 0 || value > (OAKE_LAB ? 2 : 1))
+        return fail(h, OAKE_ERR_INVALID, "patch_direct must be 0 or 1 (2: lab build only)");
+      h->patch_direct = value;
+      return OAKE_OK;
+    case OAKE_OPT_CU_COUNT:
+      if (value < 0 || value > 4096) return fail(h, OAKE_ERR_INVALID, "cu_count must be in 0 .. 4096");
+      h->opts.cu_count = value;
+      return OAKE_OK;
     case OAKE_OPT_FUSE_ATTN_OUT: h->fuse_attn_out = value ? 1 : 0; return OAKE_OK;
     default: return fail(h, OAKE_ERR_INVALID, "unknown option " + std::to_string(option));
   }

@@ -20,6 +20,13 @@
 #include "common.h"
 #include "kernels.h"
 
+// -DOAKE_LAB=1 (liboake_hip_lab.so): the production kernels plus the forms that lost their A/B — V fragments by
+// 16-bit LDS gathers, 64 queries per wave, the eight-wave blocks, the whole-K/V-in-LDS kernel — selectable by
+// attention_variant.  The production library runs variant 31 only.
+#ifndef OAKE_LAB
+#define OAKE_LAB 0
+#endif
+
 namespace oake {
 
 namespace {
@@ -877,307 +884,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   }
 }
 
-// attention_full_kernel (attention_variant bit 64; a measured experiment, OFF by default): 64 < L <= 208
-// (objects mode L = 197, text L = 77) — the cooperative kernel's arithmetic with the memory side of
-// attention_pair_kernel.  attention_coop_kernel walks the keys in 64-key chunks: every chunk is fetched into
-// registers one chunk ahead, published to LDS and fenced by two block barriers (four global round trips and
-// eight barriers per block at L = 197).  RESULT: 12.8 ms per objects step against the cooperative kernel's
-// 12.7 — at the same 12 waves per CU neither the barriers nor the exposed round trips were what bounds it
-// (nor its HBM bytes: the XCD-aware block order cut them by 29 % for 3 %; nor the per-score VALU work: a
-// straight-line path for full chunks changed nothing).  Here the block's four waves pull the
-// WHOLE K and V of their (crop, head) into LDS up front with LDS-DMA (25 + 25 pieces of 8 rows x 128 B, all in
-// flight at once, no registers), wait once, and then run the key chunks back to back with no barrier and no
-// global access in the loop.
-//   LDS: [V rows 0..R) [K rows 0..R), R = L rounded up to 16, rows of 128 B with the 16-B chunks XOR-swizzled
-//   by (row >> 1) & 7 on the source side (gemm.hip / attention_pair_kernel): conflict-free ds_read_b128 K
-//   fragments and ds_read_b64_tr_b16 V fragments without padding.  53 KB at L = 197: three blocks per CU.
-//   V rows [L, R) are zeroed (their P is exactly 0, the data must be finite); a 32-key PV half that reaches
-//   past R reads the first K rows (finite).  K rows past L only produce scores the key mask discards.
-//   O leaves through the K rows after a block barrier, as 8 rows x 128 B per store.
-// Block -> (crop, head, query group) as in attention_coop_kernel (the QG blocks of a head on one XCD).
-constexpr int kFullMaxL = 208;
-// (+ the objects-mode key bias, L floats: in the K rows past L — never read as data — when they hold it (L = 197:
-// 11 rows = 1408 B), else appended.  54 272 B instead of 53 248 would round to two blocks per CU.)
-__host__ __device__ constexpr int full_bias_in_pad(int L) { return (((L + 15) / 16 * 16) - L) * 128 >= L * 4; }
-__host__ __device__ constexpr int full_lds_bytes(int L, bool with_bias) {
-  return 2 * ((L + 15) / 16 * 16) * 128 + (with_bias && !full_bias_in_pad(L) ? 1024 : 0);
-}
+#if OAKE_LAB
+#include "attention_lab_full.inc"
+#endif
 
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_full_kernel(
-    const T* __restrict__ qkv, T* __restrict__ out, int L, int H, int QG, int causal, ObjArgs obj, int n_items) {
-  typedef typename T16<T>::vec8 vec8;
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-  constexpr int MT = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int qg = slot % QG;
-  const int item = (slot / QG) * 8 + xcd;
-  if (item >= n_items) return;
-  const int h = item % H;
-  const int img = item / H;
-  const int C = H * kHeadDim;
-  const size_t ld = (size_t)3 * C;
-  const T* base = qkv + (size_t)img * L * ld + h * kHeadDim;
-  const int R = (L + 15) & ~15;
-  char* vs = smem;
-  char* ks = smem + R * 128;
-  // objects mode: -100 * mask of the crop's patch keys, indexed by key
-  float* mbias = reinterpret_cast<float*>(full_bias_in_pad(L) ? ks + L * 128 : smem + 2 * R * 128);
-  const int fr = lane & 15;
-  const int g = lane >> 4;
-  const int fsw = (fr >> 1) & 7;
-  const int q0 = qg * 128 + wid * 32;
-  const bool is_obj = obj.qkv_y != nullptr && qg == QG - 1 && q0 >= L && q0 - 32 < L;
-  const bool active = q0 < L || is_obj;
-  const T* yb = reinterpret_cast<const T*>(obj.qkv_y) + (size_t)img * ld + h * kHeadDim;
-
-  // K and V -> LDS: piece p < NP is K rows [8 p, 8 p + 8), piece NP + p the same rows of V; wave w issues
-  // pieces w, w + 4, ... (lanes past row L - 1 stay off)
-  {
-    const int NP = (L + 7) >> 3;
-    for (int pc = wid; pc < 2 * NP; pc += 4) {
-      const bool is_v = pc >= NP;
-      const int jr = is_v ? pc - NP : pc;
-      const int row = jr * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      if (row < L)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (size_t)row * ld + (is_v ? 2 * C : C) + chunk * 8),
-                                         (lds_ptr_t)((is_v ? vs : ks) + jr * 1024), 16, 0, 0);
-    }
-    // V rows [L, R): zero (16-B pieces; at most 15 rows x 8 pieces)
-    for (int i = tid; i < (R - L) * 8; i += 256)
-      *reinterpret_cast<uint4*>(vs + (L + (i >> 3)) * 128 + (i & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
-  }
-
-  vec8 qf[MT][2];
-  float s_self = 0.f;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    int r = q0 + mt * 16 + fr;
-    r = r < L ? r : L - 1;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      qf[mt][kk] = is_obj ? *reinterpret_cast<const vec8*>(yb + kk * 32 + g * 8)
-                          : *reinterpret_cast<const vec8*>(base + (size_t)r * ld + kk * 32 + g * 8);
-  }
-  if (obj.qkv_y != nullptr && qg == QG - 1) {
-    float mval = 0.f;
-    if (tid >= 1 && tid < L)
-      mval = obj.mask_f16 ? (float)reinterpret_cast<const f16_t*>(obj.mask)[(size_t)img * (L - 1) + tid - 1]
-                          : reinterpret_cast<const float*>(obj.mask)[(size_t)img * (L - 1) + tid - 1];
-    mbias[tid] = -100.0f * mval;
-  }
-  if (is_obj) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const vec8 kv = *reinterpret_cast<const vec8*>(yb + C + kk * 32 + g * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s_self += to32<T>(qf[0][kk][j]) * to32<T>(kv[j]);
-    }
-    s_self = rows16_sum(s_self);
-  }
-  float m_run[MT], l_run[MT];
-  f32x4 oacc[4][MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    m_run[mt] = -1e30f;
-    l_run[mt] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): this wave's pieces, Q rows and zero rows are in
-  __syncthreads();
-
-  const int nmt = is_obj ? 1 : (q0 >= L ? 0 : (L - q0 > 16 ? 2 : 1));
-  const int nchunks = (L + 63) >> 6;
-  if (active)
-  for (int kc = 0; kc < nchunks; ++kc) {
-    const int k0 = kc * 64;
-    if (causal && !is_obj && k0 > q0 + 31) break;  // every later chunk is masked out completely
-    const int nkt = L - k0 >= 64 ? 4 : (L - k0 + 15) >> 4;
-    const int nks = (nkt + 1) >> 1;
-    const bool fast = !is_obj && !causal && nmt == 2 && L - k0 >= 64;  // (nkt == 4 also holds for 49..63 keys)
-    f32x4 sacc[4][MT];
-    if (fast) {
-      const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const char* krow = ks + (k0 + kt * 16 + fr) * 128;
-        const vec8 kf0 = *reinterpret_cast<const vec8*>(krow + (((0 + g) ^ fsw) << 4));
-        const vec8 kf1 = *reinterpret_cast<const vec8*>(krow + (((4 + g) ^ fsw) << 4));
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          sacc[kt][mt] = T16<T>::mfma(kf0, qf[mt][0], zero4);
-          sacc[kt][mt] = T16<T>::mfma(kf1, qf[mt][1], sacc[kt][mt]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        if (kt < nkt) {
-          const char* krow = ks + (k0 + kt * 16 + fr) * 128;
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const vec8 kf = *reinterpret_cast<const vec8*>(krow + (((kk * 4 + g) ^ fsw) << 4));
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              if (mt < nmt) sacc[kt][mt] = T16<T>::mfma(kf, qf[mt][kk], sacc[kt][mt]);
-          }
-        }
-      }
-    }
-    vec8 pf[MT][2];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (mt >= nmt) continue;
-      float mx = -1e30f;
-      if (fast) {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][mt][r]);
-      } else if (is_obj) {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          if (kt >= nkt) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = k0 + kt * 16 + 4 * g + r;
-            float sv = sacc[kt][mt][r];
-            sv = key == 0 ? s_self : (key < L ? sv + mbias[key & 255] : -1e30f);
-            sacc[kt][mt][r] = sv;
-            mx = fmaxf(mx, sv);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          if (kt >= nkt) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = k0 + kt * 16 + 4 * g + r;
-            float sv = sacc[kt][mt][r];
-            sv = (key < L && (!causal || key <= q0 + mt * 16 + fr)) ? sv : -1e30f;
-            sacc[kt][mt][r] = sv;
-            mx = fmaxf(mx, sv);
-          }
-        }
-      }
-      mx = rows16_max(mx);
-      const float m_new = fmaxf(m_run[mt], mx);
-      const float alpha = __expf(m_run[mt] - m_new);
-      const float nb = -m_new * kLog2e;
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        if (fast || kt < nkt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][mt][r], kLog2e, nb));
-            sacc[kt][mt][r] = pv;
-            sum += pv;
-          }
-        } else {
-          sacc[kt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      sum = rows16_sum(sum);
-      l_run[mt] = l_run[mt] * alpha + sum;
-      m_run[mt] = m_new;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        oacc[dt][mt][0] *= alpha;
-        oacc[dt][mt][1] *= alpha;
-        oacc[dt][mt][2] *= alpha;
-        oacc[dt][mt][3] *= alpha;
-      }
-#pragma unroll
-      for (int ksx = 0; ksx < 2; ++ksx) {
-        vec8 p8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) p8[j] = to16<T>(sacc[2 * ksx + (j >> 2)][mt][j & 3]);
-        pf[mt][ksx] = p8;
-      }
-    }
-#pragma unroll
-    for (int ksx = 0; ksx < 2; ++ksx) {
-      if (!fast && ksx >= nks) continue;
-      const int row0 = k0 + 32 * ksx + 4 * g + (fr >> 2);  // and row0 + 16: same swizzle
-      const int vsw = (row0 >> 1) & 7;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int c4 = (fr & 3) * 4;
-        const char* p0 = vs + row0 * 128 + (((dt * 2 + (c4 >> 3)) ^ vsw) << 4) + (c4 & 4) * 2;
-        typedef s16x4 __attribute__((address_space(3))) * lds4_t;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 16 * 128));
-        s16x8 both;
-        both[0] = lo[0]; both[1] = lo[1]; both[2] = lo[2]; both[3] = lo[3];
-        both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
-        const vec8 vf = __builtin_bit_cast(vec8, both);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          if (fast || mt < nmt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ksx], oacc[dt][mt]);
-      }
-    }
-  }
-  __syncthreads();  // every wave is done with K / V: the K rows become the output staging area
-  if (!active) return;
-  if (is_obj) {
-    const float inv = 1.0f / l_run[0];
-    const float p0 = __expf(s_self - m_run[0]) * inv;
-    T* oy = reinterpret_cast<T*>(obj.out_y) + (size_t)img * C + h * kHeadDim;
-    if (fr == 0) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int d = dt * 16 + 4 * g;
-        typedef typename T16<T>::vec4 vec4;
-        const vec4 vy = __builtin_bit_cast(vec4, *reinterpret_cast<const uint2*>(yb + 2 * C + d));
-        const vec4 vc = __builtin_bit_cast(vec4, *reinterpret_cast<const uint2*>(base + 2 * C + d));
-        const f32x4 o = oacc[dt][0];
-        *reinterpret_cast<uint2*>(oy + d) =
-            pack4<T>(o[0] * inv + p0 * (to32<T>(vy[0]) - to32<T>(vc[0])),
-                     o[1] * inv + p0 * (to32<T>(vy[1]) - to32<T>(vc[1])),
-                     o[2] * inv + p0 * (to32<T>(vy[2]) - to32<T>(vc[2])),
-                     o[3] * inv + p0 * (to32<T>(vy[3]) - to32<T>(vc[3])));
-      }
-    }
-    return;
-  }
-  // O -> rows [32 wid, 32 wid + 32) of the K region (swizzled like every row) -> 8 rows x 128 B per store
-  T* obase = out + (size_t)img * L * C + h * kHeadDim;
-  const int srow0 = wid * 32;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if (mt >= nmt) continue;
-    const float inv = 1.0f / l_run[mt];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const f32x4 o = oacc[dt][mt];
-      *reinterpret_cast<uint2*>(ks + (srow0 + mt * 16 + fr) * 128 + (((dt * 2 + (g >> 1)) ^ fsw) << 4) + (g & 1) * 8) =
-          pack4<T>(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int i = 0; i < 2 * MT; ++i) {
-    const int row = (lane >> 3) + 8 * i;
-    const int srow = srow0 + row;
-    const uint4 v = *reinterpret_cast<const uint4*>(ks + srow * 128 + (((lane & 7) ^ ((srow >> 1) & 7)) << 4));
-    if (row < nmt * 16 && q0 + row < L) *reinterpret_cast<uint4*>(obase + (size_t)(q0 + row) * C + (lane & 7) * 8) = v;
-  }
-}
 
 __global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[256];
@@ -1204,7 +914,12 @@ namespace {
 struct AttnBits {
   bool use_tr, q32, coop, fuse_obj, pair, coop8, full;
   explicit AttnBits(const LaunchOpts* o) {
+#if OAKE_LAB
     const int v = o ? o->attention_variant : 31;
+#else
+    const int v = 31;  // (production: the one configuration; oake_set_option rejects the others)
+    (void)o;
+#endif
     use_tr = v & 1; q32 = v & 2; coop = v & 4; fuse_obj = v & 8; pair = v & 16; coop8 = v & 32; full = v & 64;
   }
 };
@@ -1218,10 +933,12 @@ static void attn_launch_t(const void* qkv, void* out, int n, int L, int heads, i
   const dim3 g((tw + 3) / 4), b(256);
   const T* in = reinterpret_cast<const T*>(qkv);
   T* o = reinterpret_cast<T*>(out);
-  if (use_tr)
-    OAKE_LAUNCH((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
-  else
+#if OAKE_LAB
+  if (!use_tr)
     OAKE_LAUNCH((attention_kernel<T, false, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
+  else
+#endif
+    OAKE_LAUNCH((attention_kernel<T, true, MT>), g, b, 0, s, in, o, L, heads, QB, tw, causal);
 }
 
 template <typename T>
@@ -1236,10 +953,22 @@ static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, i
   return hipGetLastError();
 }
 
+bool attention_variant_supported(int v) {
+#if OAKE_LAB
+  return v >= 0 && v <= 127;
+#else
+  return v == 31;
+#endif
+}
+
 bool attention_fuses_object_token(int L, const LaunchOpts* opts) {
   // needs the cooperative kernel and a wave without queries in the last block of each head
   const AttnBits b(opts);
+#if OAKE_LAB
   const bool full = b.full && L <= kFullMaxL;                  // attention_full_kernel: four waves per block
+#else
+  const bool full = false;
+#endif
   const int per = !full && b.coop8 && L > 128 ? 256 : 128;     // queries per block
   const int tail = L - per * ((L + per - 1) / per - 1);
   return b.coop && b.use_tr && b.fuse_obj && L > 64 && L <= 256 && tail <= per - 32;
@@ -1254,6 +983,7 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
   if (qkv_y != nullptr && mask_dtype != DT_F32 && mask_dtype != DT_F16) return hipErrorInvalidValue;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
+#if OAKE_LAB
   if (bits.coop && bits.use_tr && bits.full && L > 64 && L <= kFullMaxL) {
     const int QG = (L + 127) / 128;
     const int n_items = n * heads;
@@ -1280,6 +1010,7 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
     }
     return hipGetLastError();
   }
+#endif
   if (bits.coop && bits.use_tr && L > 64) {
     const bool eight = bits.coop8 && L > 128;
     const int per = eight ? 256 : 128;
@@ -1288,17 +1019,21 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
     const dim3 grid(((n_items + 7) / 8) * 8 * QG), blk(eight ? 512 : 256);
     const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
     if (dtype16 == DT_F16) {
+#if OAKE_LAB
       if (eight)
         OAKE_LAUNCH((attention_coop_kernel<f16_t, 8>), grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
                     reinterpret_cast<f16_t*>(out), L, heads, QG, causal, obj, n_items);
       else
+#endif
         OAKE_LAUNCH((attention_coop_kernel<f16_t, 4>), grid, blk, 0, s, reinterpret_cast<const f16_t*>(qkv),
                     reinterpret_cast<f16_t*>(out), L, heads, QG, causal, obj, n_items);
     } else if (dtype16 == DT_BF16) {
+#if OAKE_LAB
       if (eight)
         OAKE_LAUNCH((attention_coop_kernel<bf16_t, 8>), grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
                     reinterpret_cast<bf16_t*>(out), L, heads, QG, causal, obj, n_items);
       else
+#endif
         OAKE_LAUNCH((attention_coop_kernel<bf16_t, 4>), grid, blk, 0, s, reinterpret_cast<const bf16_t*>(qkv),
                     reinterpret_cast<bf16_t*>(out), L, heads, QG, causal, obj, n_items);
     } else {
@@ -1312,11 +1047,17 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
     return hipErrorInvalidValue;
   }
   if (dtype16 == DT_F16) {
-    if (bits.q32) attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, causal, s, bits.use_tr);
-    else attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, causal, s, bits.use_tr);
+#if OAKE_LAB
+    if (!bits.q32) attn_launch_t<f16_t, 4>(qkv, out, n, L, heads, causal, s, bits.use_tr);
+    else
+#endif
+      attn_launch_t<f16_t, 2>(qkv, out, n, L, heads, causal, s, bits.use_tr);
   } else if (dtype16 == DT_BF16) {
-    if (bits.q32) attn_launch_t<bf16_t, 2>(qkv, out, n, L, heads, causal, s, bits.use_tr);
-    else attn_launch_t<bf16_t, 4>(qkv, out, n, L, heads, causal, s, bits.use_tr);
+#if OAKE_LAB
+    if (!bits.q32) attn_launch_t<bf16_t, 4>(qkv, out, n, L, heads, causal, s, bits.use_tr);
+    else
+#endif
+      attn_launch_t<bf16_t, 2>(qkv, out, n, L, heads, causal, s, bits.use_tr);
   } else {
     return hipErrorInvalidValue;
   }

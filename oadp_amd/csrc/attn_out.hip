@@ -42,6 +42,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef OAKE_LAB
+#define OAKE_LAB 0  // 1: liboake_hip_lab.so (adds the s_memtime-stamped measurement build of the kernel)
+#endif
+
 namespace oake {
 
 namespace {
@@ -478,8 +482,13 @@ hipError_t launch_attn_out(int dtype16, const void* qkv, const void* wperm, cons
                            float* rowpart, int n, int L, hipStream_t s, unsigned long long* trace) {
   if (n <= 0) return hipSuccess;
   if (L < 1 || L > 64) return hipErrorInvalidValue;
-  if (trace != nullptr)  // measurement: phase stamps of the first workgroups (f16 only)
+  if (trace != nullptr) {  // measurement: phase stamps of the first workgroups (f16 only; lab build)
+#if OAKE_LAB
     return attn_out_launch_t<f16_t, true>(qkv, wperm, bias, x, rowpart, n, L, trace, s);
+#else
+    return hipErrorInvalidValue;
+#endif
+  }
   return dtype16 == DT_BF16 ? attn_out_launch_t<bf16_t, false>(qkv, wperm, bias, x, rowpart, n, L, nullptr, s)
                             : attn_out_launch_t<f16_t, false>(qkv, wperm, bias, x, rowpart, n, L, nullptr, s);
 }

@@ -34,6 +34,13 @@
 #include "common.h"
 #include "kernels.h"
 
+// -DOAKE_LAB=1 builds liboake_hip_lab.so: the production kernels PLUS every tile configuration, kernel form and
+// measurement epilogue that lost its A/B (tools/, the variant tests).  The production library carries only what
+// pick_variant() can select.
+#ifndef OAKE_LAB
+#define OAKE_LAB 0
+#endif
+
 namespace oake {
 
 namespace {
@@ -752,155 +759,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_deep_kernel(const T* __restr
                                 m0 + BM <= M && n0 + BN <= N);
 }
 
-// ---------------------------------------------------------------------------------------------
-// One-tile-per-block kernel with ONE compute wave per SIMD (experiment; variant 7):
-// 4 compute waves of BM x 64 (10 x 4 accumulator tiles = 160 registers, 2 waves per SIMD = 256 each)
-// + 4 DMA waves.  A compute wave streams its 80 MFMAs per K-tile with the fragment reads
-// software-pipelined under them (tools/ubench/mfma_stream.hip: 17.7 cycles per MFMA against the 19.8 of
-// the alternating-phase layout), two barriers per K-tile.  Ring of 3 stages: barrier g (start of K-tile
-// g) frees K-tile g - 1's stage for the DMA of g + 2; barrier g' (80 % through K-tile g) publishes K-tile
-// g + 1, whose first fragments the stream prefetches under the last MFMAs of g — so a K-tile has 1.8
-// K-tiles of time to land.
-template <typename T, int EPI, int BM, int BN>
-__global__ __launch_bounds__(512) void gemm_q4_kernel(const T* __restrict__ A, const T* __restrict__ W, int M,
-                                                      int N, int K, EpiParams ep, TileMap tmap) {
-  typedef typename T16<T>::vec8 vec8;
-  constexpr bool PAIRED = EpiTraits<EPI>::kPaired;
-  static_assert(BN == 256 && BM % 16 == 0, "four compute waves of BM x 64");
-  constexpr int MI = BM / 16, NI = 4, TN = 64;
-  constexpr int kATileBytes = BM * kRowBytes;
-  constexpr int kStageBytes = (BM + BN) * kRowBytes;
-  constexpr int NINST = (BM + BN) / 8;
-  static_assert(NINST % 4 == 0, "pieces split evenly over the DMA waves");
-  constexpr int NPL = NINST / 4;
-  constexpr int NSTAGE = 3;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int m0, n0;
-  tile_origin(tmap, xcd_remap(blockIdx.x, tmap.nwg), BM, BN, m0, n0);
-  const int nk = K / BK;
-  char* elds = smem + NSTAGE * kStageBytes;
-#define OAKE_Q4_BAR()                  \
-  do {                                 \
-    __builtin_amdgcn_sched_barrier(0); \
-    __builtin_amdgcn_s_barrier();      \
-    __builtin_amdgcn_sched_barrier(0); \
-  } while (0)
-
-  if (wid >= 4) {
-    // ================= DMA wave =================
-    const int lw = wid - 4;
-    const char* src[NPL];
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + 4 * j, lane);
-#define OAKE_Q4_STAGE(kt_)                                                                       \
-  do {                                                                                           \
-    char* _base = smem + ((kt_) % NSTAGE) * kStageBytes;                                         \
-    const size_t _koff = (size_t)(kt_) * (BK * 2);                                               \
-    _Pragma("unroll") for (int _j = 0; _j < NPL; ++_j)                                           \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                           \
-                                         (lds_ptr_t)(_base + (lw + 4 * _j) * 1024), 16, 0, 0);   \
-  } while (0)
-    if (lw == 0 && ep.bias != nullptr && EPI != EPI_PATCH && EPI != EPI_PATCH16) {
-      int n = n0 + 4 * lane;
-      n = n + 4 <= N ? n : N - 4;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.bias + n), (lds_ptr_t)(elds + EpiLds::kBias), 16, 0, 0);
-    }
-    // vmcnt immediate: bits [3:0] | [15:14]; expcnt 7 and lgkmcnt 15 = "don't wait"
-#define OAKE_Q4_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
-    OAKE_Q4_STAGE(0);
-    if (nk > 1) OAKE_Q4_STAGE(1);
-    if (nk > 1) OAKE_Q4_VMCNT(NPL); else OAKE_Q4_VMCNT(0);  // K-tile 0 has landed
-    for (int g = 0; g < nk; ++g) {
-      OAKE_Q4_BAR();  // barrier g (start of K-tile g): K-tile g is readable, K-tile g - 1's stage is free
-      if (g + 2 < nk) {
-        OAKE_Q4_STAGE(g + 2);
-        OAKE_Q4_VMCNT(NPL);  // K-tile g + 1 (issued a K-tile ago) has landed; g + 2 stays in flight
-      } else {
-        OAKE_Q4_VMCNT(0);
-      }
-      OAKE_Q4_BAR();  // barrier g' (80 % through K-tile g): K-tile g + 1 is readable
-    }
-#undef OAKE_Q4_VMCNT
-#undef OAKE_Q4_STAGE
-    return;
-  }
-
-  // ================= compute wave =================
-  const int wn = wid;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int fsw = (fr >> 1) & 7;
-  const int a_off = fr * kRowBytes, b_off = kATileBytes + (wn * TN + fr) * kRowBytes;
-  const int kx0 = ((0 * 4 + fg) ^ fsw) << 4, kx1 = ((1 * 4 + fg) ^ fsw) << 4;
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  vec8 bf[2][NI];
-  vec8 af[5];
-  // tools/gemm_trace.py (record layout of gemm_pp_kernel); only where the registers allow it
-  unsigned long long* const trace = EPI == EPI_RESID16 ? tmap.trace : nullptr;
-  const unsigned long long t_entry = trace ? __builtin_readcyclecounter() : 0;
-  if (trace != nullptr && tid == 0) trace[4096 + (blockIdx.x & 255) * 2] = wall_clock64();
-  OAKE_Q4_BAR();  // barrier 0
-  {
-    const char* st = smem;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) bf[0][j] = *reinterpret_cast<const vec8*>(st + b_off + j * 16 * kRowBytes + kx0);
-    af[0] = *reinterpret_cast<const vec8*>(st + a_off + kx0);
-    af[1] = *reinterpret_cast<const vec8*>(st + a_off + 16 * kRowBytes + kx0);
-  }
-  int stage = 0;
-  const unsigned long long t_loop = trace ? __builtin_readcyclecounter() : 0;
-  for (int g = 0; g < nk; ++g) {
-    if (g > 0) OAKE_Q4_BAR();  // barrier g (the fragments prefetched for this K-tile are already in flight)
-    const char* st = smem + stage * kStageBytes;
-    const int nstage = stage == NSTAGE - 1 ? 0 : stage + 1;
-    const char* sn = smem + nstage * kStageBytes;  // K-tile g + 1 (landed by barrier g), if any
-    const bool more = g + 1 < nk;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int kx = hh == 0 ? kx0 : kx1, kxn = hh == 0 ? kx1 : kx0;
-      const char* a0 = st + a_off + kx;
-      // the next half: the other kk of this K-tile, or kk = 0 of K-tile g + 1
-      const char* an = (hh == 0 ? st : sn) + a_off + kxn;
-      const char* bn = (hh == 0 ? st : sn) + b_off + kxn;
-      const bool pre = hh == 0 || more;
-      // B fragments of the next half: early in half 0 (same K-tile), late in half 1 (next K-tile: it is
-      // readable only behind barrier g', placed before row block MI - NI of half 1)
-      const int b_first = hh == 0 ? 2 : MI - NI;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (hh == 1 && mi == b_first) OAKE_Q4_BAR();  // barrier g'
-        const int cur = mi % 5, nxt = (mi + 2) % 5;
-        if (mi + 2 < MI)
-          af[nxt] = *reinterpret_cast<const vec8*>(a0 + (mi + 2) * 16 * kRowBytes);
-        else if (pre)
-          af[nxt] = *reinterpret_cast<const vec8*>(an + (mi + 2 - MI) * 16 * kRowBytes);
-        if (mi >= b_first && mi < b_first + NI && pre)
-          bf[hh ^ 1][mi - b_first] = *reinterpret_cast<const vec8*>(bn + (mi - b_first) * 16 * kRowBytes);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[mi][j] = T16<T>::mfma(bf[hh][j], af[cur], acc[mi][j]);
-        if (mi >= b_first && mi < b_first + NI) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      }
-    }
-    stage = nstage;
-  }
-#undef OAKE_Q4_BAR
-  const unsigned long long t_ep = trace ? __builtin_readcyclecounter() : 0;
-  tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + fr, n0 + wn * TN, fg, M, N, ep, false,
-                                    m0 + BM <= M && n0 + BN <= N, elds, wn * TN, fr);
-  if (trace != nullptr && tid == 0 && blockIdx.x < 64) {
-    unsigned long long* tr = trace + ((size_t)blockIdx.x * 2 * 8) * 4;
-    tr[0] = t_entry; tr[1] = t_loop; tr[2] = t_ep; tr[3] = __builtin_readcyclecounter();
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    trace[4096 + (blockIdx.x & 255) * 2 + 1] = wall_clock64();
-  }
-}
+#if OAKE_LAB
+#include "gemm_lab_q4.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Production kernel: persistent, ping-pong compute waves + dedicated DMA waves.
@@ -1429,221 +1290,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Two workgroups per CU: half-width tiles (BM x 128), each workgroup = 4 compute waves (one per SIMD,
-// 80 x 64 wave tiles) + 2 DMA waves, 2-slot LDS ring (72 KB) + the EpiLds block, so that TWO
-// workgroups fit one CU (12 waves = 3 per SIMD, 168 registers).  Nothing synchronises the two: while
-// one runs its tile-end epilogue (VALU + stores, the matrix pipe idle in a lone workgroup) the other is
-// somewhere in its K loop — the overlap the ping-pong kernel's lock-stepped groups cannot have, because
-// both of its groups reach the tile end together.  The price: 1.38x the LDS-DMA bytes per FLOP
-// ((160 + 128) vs (160 + 256) rows per K-tile for half the columns).
-//   per K-tile:   BAR | 18 fragment reads | 40 MFMAs            (compute waves)
-//                 BAR | issue K-tile g+1 into the other slot | vmcnt(0)   (DMA waves)
-// The barrier of K-tile g publishes K-tile g (the DMA waves waited for it) and frees the slot of K-tile
-// g-1 (every compute wave has read it).  At a tile's first K-tile the DMA waves also stage that tile's
-// bias / colsum / row statistics into EpiLds: every compute wave is past the previous tile's epilogue.
-template <typename T, int EPI, int BM, int BN>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_duo_kernel(
-    const T* __restrict__ A, const T* __restrict__ W, int M, int N, int K, EpiParams ep, TileMap tmap) {
-  typedef typename T16<T>::vec8 vec8;
-  constexpr bool PAIRED = EpiTraits<EPI>::kPaired;
-  constexpr int WM = 2, WN = 2, NW = WM * WN, NL = 4;
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int MI = TM / 16, NI = TN / 16;
-  constexpr int kATileBytes = BM * kRowBytes;
-  constexpr int kStageBytes = (BM + BN) * kRowBytes;
-  constexpr int NINST = (BM + BN) / 8;
-  static_assert(NINST % NL == 0 && (BM / 8) % NL == 0, "pieces split evenly over the DMA waves");
-  constexpr int NPL = NINST / NL;
-  constexpr int kAPieces = BM / 8 / NL;
-  static_assert(TM % 16 == 0 && TN % 32 == 0, "tile shape");
-  constexpr int NSTAGE = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nx = 8;
-  const int xcd = blockIdx.x % nx, xslot = blockIdx.x / nx;
-  const int per_xcd = gridDim.x / nx;
-  const int q = tmap.nwg / nx, r = tmap.nwg % nx;
-  const int xb = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int xc = xcd < r ? q + 1 : q;
-  const int my_tiles = xslot < xc ? (xc - xslot + per_xcd - 1) / per_xcd : 0;
-  if (my_tiles == 0) return;
-  const int nk = K / BK;
-  const int total = my_tiles * nk;
-  char* const elds_w = smem + NSTAGE * kStageBytes;
-
-#define OAKE_PIN() __builtin_amdgcn_sched_barrier(0)
-#define OAKE_BAR()                   \
-  do {                               \
-    OAKE_PIN();                      \
-    __builtin_amdgcn_s_barrier();    \
-    OAKE_PIN();                      \
-  } while (0)
-
-  if (wid >= NW) {
-    // ================= DMA wave =================
-    const int lw = wid - NW;
-    const char* src[NPL];
-    auto set_src = [&](int tile_i) {
-      int m0, n0;
-      tile_origin(tmap, xb + xslot + tile_i * per_xcd, BM, BN, m0, n0);
-#pragma unroll
-      for (int j = 0; j < NPL; ++j)
-        src[j] = piece_src<T, BM, TN, PAIRED>(A, W, M, N, K, m0, n0, lw + NL * j, lane, ep.patch_S,
-                                              ep.patch_P, ep.patch_G, ep.patch_T, ep.patch_H);
-    };
-    int s_kt = 0, s_tile = 0;  // producer cursor: K-tile s_kt of tile s_tile goes to slot (flat index) & 1
-    int d_kt = 0, d_tile = 0;  // the K-tile the compute waves work on
-#define OAKE_DUO_STAGE(buf_)                                                                       \
-  do {                                                                                           \
-    char* _base = smem + (buf_) * kStageBytes;                                                   \
-    const size_t _koff = (size_t)s_kt * (BK * 2);                                                \
-    const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P, ep.patch_H) : _koff;    \
-    _Pragma("unroll") for (int _j = 0; _j < NPL; ++_j)                                           \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + (_j < kAPieces ? _koffa : _koff)), \
-                                         (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, 0);  \
-    if (++s_kt == nk) {                                                                          \
-      s_kt = 0;                                                                                  \
-      if (++s_tile < my_tiles) set_src(s_tile);                                                  \
-    }                                                                                            \
-  } while (0)
-    constexpr bool LN = EpiTraits<EPI>::kLn;
-    constexpr int RPW = BM / NL;  // rows per DMA wave: lanes take row `lane` and, below RPW - 64, row 64 + lane
-    static_assert(RPW <= 128, "two rows per lane at most");
-    set_src(0);
-    OAKE_DUO_STAGE(0);
-    for (int g = 0; g < total; ++g) {
-      float st_rstd[2] = {0.f, 0.f}, st_shift[2] = {0.f, 0.f};
-      if constexpr (LN) {
-        if (d_kt == 0) {
-          int _m0, _n0;
-          tile_origin(tmap, xb + xslot + d_tile * per_xcd, BM, BN, _m0, _n0);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (64 * h + lane < RPW) {
-              int _m = _m0 + lw * RPW + 64 * h + lane;
-              _m = _m < M ? _m : M - 1;
-              const float4* _p = reinterpret_cast<const float4*>(ep.rowpart_in + (size_t)_m * kRowParts);
-              float4 _v[kRowParts / 2];
-#pragma unroll
-              for (int i = 0; i < kRowParts / 2; ++i)
-                _v[i] = 2 * i < ep.nparts ? _p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-              float _s1 = 0.f, _s2 = 0.f;
-#pragma unroll
-              for (int i = 0; i < kRowParts / 2; ++i) {
-                _s1 += _v[i].x;
-                _s2 += _v[i].y;
-                if (2 * i + 1 < ep.nparts) {
-                  _s1 += _v[i].z;
-                  _s2 += _v[i].w;
-                }
-              }
-              const float _mean = _s1 * ep.inv_k;
-              const float _var = fmaxf(_s2 * ep.inv_k - _mean * _mean, 0.f);
-              st_rstd[h] = rsqrtf(_var + 1e-5f);
-              st_shift[h] = -_mean * st_rstd[h];
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0), lgkmcnt(0): K-tile g (and the EpiLds block) landed
-      OAKE_BAR();  // publishes K-tile g; K-tile g-1's slot and, at a tile's first K-tile, EpiLds are free
-      if (g + 1 < total) OAKE_DUO_STAGE((g + 1) & 1);
-      if (d_kt == 0) {
-        int _m0, _n0;
-        tile_origin(tmap, xb + xslot + d_tile * per_xcd, BM, BN, _m0, _n0);
-        int _n = _n0 + 4 * lane;
-        _n = _n + 4 <= N ? _n : N - 4;
-        if (lane < BN / 4) {
-          if (lw == 0 && ep.bias != nullptr && EPI != EPI_PATCH && EPI != EPI_PATCH16)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.bias + _n), (lds_ptr_t)(elds_w + EpiLds::kBias), 16, 0, 0);
-          if (LN && lw == 1)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ep.colsum + _n), (lds_ptr_t)(elds_w + EpiLds::kColsum), 16, 0, 0);
-        }
-        if constexpr (LN) {
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          typedef __attribute__((address_space(3))) f32x2* lds_f2w_t;
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-            if (64 * h + lane < RPW)
-              *(lds_f2w_t)(elds_w + EpiLds::kRowstat + (lw * RPW + 64 * h + lane) * 8) =
-                  f32x2{st_rstd[h], st_shift[h]};
-        }
-      }
-      if (++d_kt == nk) {
-        d_kt = 0;
-        ++d_tile;
-      }
-    }
-#undef OAKE_DUO_STAGE
-    return;
-  }
-
-  // ================= compute wave =================
-  const int wm = wid / WN, wn = wid % WN;
-  const int frow = lane & 15;
-  const int fg = lane >> 4;
-  const int fsw = (frow >> 1) & 7;
-  const int a_base = (wm * TM + frow) * kRowBytes;
-  const int b_base = kATileBytes + (wn * TN + frow) * kRowBytes;
-  const int koff0 = ((0 * 4 + fg) ^ fsw) << 4;
-  const int koff1 = ((1 * 4 + fg) ^ fsw) << 4;
-  const char* elds = elds_w;
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int c_buf = 0, c_kt = 0, c_tile = 0;
-  for (int g = 0; g < total; ++g) {
-    OAKE_BAR();
-    {
-      vec8 af[MI], bf[NI], af1[MI], bf1[NI];
-      const char* _st = smem + c_buf * kStageBytes;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff0);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) bf[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff0);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af1[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff1);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) bf1[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff1);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf1[ni], af1[mi], acc[mi][ni]);
-    }
-    c_buf ^= 1;
-    if (++c_kt == nk) {
-      c_kt = 0;
-      int m0, n0;
-      tile_origin(tmap, xb + xslot + c_tile * per_xcd, BM, BN, m0, n0);
-      ++c_tile;
-      OAKE_PIN();
-      // lane coordinates re-derived behind an opaque asm: hipcc would otherwise keep every epilogue address
-      // in a VGPR across the K loop
-      int etid = tid;
-      asm volatile("" : "+v"(etid));
-      const int efrow = etid & 15, efg = (etid & 63) >> 4;
-      tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + wm * TM + efrow, n0 + wn * TN, efg, M, N, ep, false,
-                                        m0 + BM <= M && n0 + BN <= N, elds, wn * TN, wm * TM + efrow);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-#undef OAKE_PIN
-#undef OAKE_BAR
-}
+#if OAKE_LAB
+#include "gemm_lab_duo.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Register-only MFMA stream (measurement: bench.py's `roofline.sustained`, tools/ubench/mfma_power.hip):
@@ -1734,6 +1383,7 @@ hipError_t launch_deep(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+#if OAKE_LAB
 template <typename T, int EPI, int BM, int BN>
 hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
@@ -1750,6 +1400,8 @@ hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
               reinterpret_cast<const T*>(a.W), a.M, a.N, a.K, ep, tmap);
   return hipGetLastError();
 }
+
+#endif
 
 template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false, bool A32 = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
@@ -1785,6 +1437,7 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+#if OAKE_LAB
 template <typename T, int EPI, int BM, int BN>
 hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * kRowBytes + EpiLds::kBytes;
@@ -1819,6 +1472,8 @@ hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+#endif
+
 // Configurations.  0: simple 128x128 (4 waves)   1: simple 160x256 (8 waves 2x4)
 //                  2: simple 320x128 (8 waves 4x2)   3: simple 256x256 (8 waves 2x4)
 //                  4: ping-pong persistent 160x256 (8 compute + 4 DMA waves)  [production; the residual, conv1 and
@@ -1828,8 +1483,9 @@ hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
 //                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
 //                  7: one compute wave per SIMD, 160x256, one tile per block (gemm_q4_kernel; experiment)
 //                 11: two workgroups per CU, 160x128 tiles (gemm_duo_kernel; experiment)
+#if OAKE_LAB
 template <typename T, int EPI>
-hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
+hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
   if constexpr (EpiTraits<EPI>::kNone || EpiTraits<EPI>::kRaw) {  // measurement epilogues: persistent kernels only
     if (variant == 8) return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);
     if (variant == 11) return launch_duo<T, EPI, 160, 128>(a, s);
@@ -1881,6 +1537,33 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
   }
 }
 
+#endif
+
+// The production library: the configurations pick_variant() can select — 0 (simple 128x128: narrow N), 4 (the
+// persistent ping-pong kernel) and 5 (deep-ring 64x64: few-hundred-row problems).  Everything else is in the lab build.
+template <typename T, int EPI>
+hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
+#if OAKE_LAB
+  return launch_variant_lab<T, EPI>(variant, a, s);
+#else
+  if constexpr (EpiTraits<EPI>::kNone || EpiTraits<EPI>::kRaw) {
+    return hipErrorInvalidValue;  // measurement epilogues: lab build only
+  } else
+  switch (variant) {
+    case 0: return launch_simple<T, EPI, 128, 128, 2, 2>(a, s);
+    case 4:  // two long phases per K-tile where the epilogue keeps no tile pending (residual, conv1) and for the
+             // LayerNorm-folded epilogues (qkv, c_fc: all of a tile's stores at its end, full lines, written through)
+      if (a.patch_f32) return hipErrorInvalidValue;  // (fp32 conv1 gather through the DMA waves' registers: lab build)
+      if constexpr (EPI == EPI_RESID16 || EPI == EPI_PATCH16 || EPI == EPI_T16_GELU_LN || EPI == EPI_T16_BIAS_LN)
+        return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+      else
+        return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
+    case 5: return launch_deep<T, EPI, 64, 64, 2, 2>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+#endif
+}
+
 int pick_variant(const GemmArgs& a) {
   if (a.opts && a.opts->gemm_variant >= 0) return a.opts->gemm_variant;
   // few-hundred-row problems: 64x64 tiles spread over the CUs, deep ring against the per-K-tile latency
@@ -1909,6 +1592,14 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+bool gemm_variant_supported(int v) {
+#if OAKE_LAB
+  return v >= -1 && v <= 11;
+#else
+  return v == -1 || v == 0 || v == 4 || v == 5;
+#endif
+}
 
 bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts) {
   GemmArgs a{};
@@ -1947,10 +1638,14 @@ bool gemm_patch_f32_ok(int image, int patch, int stride, int padding, int M, int
                        const LaunchOpts* opts) {
   // the 16-bit gather's geometry, on the production configuration of the persistent kernel (the one instantiated
   // with the register-staged A path), 8 floats per lane = 32 contiguous bytes of a patch row
+#if OAKE_LAB
   GemmArgs a{};
   a.M = M; a.N = N; a.K = K; a.opts = opts;
   const int v = pick_variant(a);
   return gemm_patch_direct_ok(image, patch, stride, padding, M, N, K, opts) && v == 4 && patch == 32;
+#else
+  return false;  // (measured slower than im2col + GEMM with two lanes: lab build only)
+#endif
 }
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s) {

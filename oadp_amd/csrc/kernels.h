@@ -84,6 +84,8 @@ bool gemm_patch_f32_ok(int image, int patch, int stride, int padding, int M, int
 bool gemm_patch_padded_ok(int patch, int stride, int M, int N, int K, const LaunchOpts* opts = nullptr);
 
 hipError_t launch_gemm(int dtype16, int epi, const GemmArgs& a, hipStream_t s);
+// tile configurations this build of the library carries (production: -1 automatic, 0, 4, 5; lab build: -1 .. 11)
+bool gemm_variant_supported(int v);
 // true when launch_gemm runs this shape on the persistent kernel (row statistics via rowpart_*)
 bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts = nullptr);
 
@@ -139,6 +141,8 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
                             const void* mask = nullptr, int mask_dtype = 0, void* out_y = nullptr,
                             const LaunchOpts* opts = nullptr);
 bool attention_fuses_object_token(int L, const LaunchOpts* opts = nullptr);
+// attention kernel forms this build carries (production: 31 only; lab build: every bit set)
+bool attention_variant_supported(int v);
 
 // Object-token attention (oadp/oake/objects.py:232-247): one query per crop (qkv_y row n),
 // keys/values = patch rows 1..L-1 of qkv_x plus the object token's own k/v (qkv_y);

@@ -24,3 +24,10 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail('a gpu-marked test was selected but no HIP device is visible')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='session')
+def lab():
+    """liboake_hip_lab.so: the production kernels plus the experiments that lost their A/B (variant tests only)."""
+    from oadp_amd import _lib
+    return _lib.load_lab()

@@ -87,3 +87,18 @@ def test_cu_half_masks_are_complementary_and_default_exists():
     assert cumask.half_masks(256, 'pairs') == cumask.half_masks(256, 'group8')
     with pytest.raises(ValueError):
         cumask.half_masks(256, 'nonsense')
+
+
+def test_lab_library_is_a_superset_build_and_the_product_is_smaller(lib):
+    """liboake_hip_lab.so (same sources, -DOAKE_LAB=1) exports exactly the same symbols; the production library is
+    the smaller one and says it is not the lab build; nothing in the product path names the lab library."""
+    lab = _lib.load_lab()
+    def exported(path):
+        out = subprocess.run(['nm', '-D', '--defined-only', str(path)], capture_output=True, text=True, check=True).stdout
+        return set(re.findall(r' T (oake_[a-z0-9_]+)', out))
+    assert exported(_lib.LAB_PATH) == exported(_lib.LIB_PATH)
+    assert lib.oake_debug_lab_build() == 0 and lab.oake_debug_lab_build() == 1
+    assert _lib.LIB_PATH.stat().st_size < 0.6 * _lib.LAB_PATH.stat().st_size
+    for p in (ROOT / 'oadp_amd').rglob('*.py'):
+        if p.name not in ('_lib.py', 'build.py'):
+            assert 'load_lab' not in p.read_text() and 'liboake_hip_lab' not in p.read_text(), p

@@ -255,8 +255,14 @@ def test_conv1_fp32_input_gathered_without_im2col(cuda, dtype):
     operand bits as the im2col route => bit-identical features; no `im2col` launch in the profile.  128 crops =
     full tiles, 45 = a ragged last tile (row clamp), 300 = three passes; one crop = the small-problem fallback."""
     sd = synthetic_state_dict()
-    direct, _ = clip.load(sd, compute_dtype=dtype, max_batch=128)
-    direct.visual.set_option('patch_direct', 2)  # opt-in: measured slower than im2col + GEMM with two lanes
+    from oadp_amd import _lib
+    # (opt-in, measured slower than im2col + GEMM with two lanes: the lab build carries it, the product refuses it)
+    direct, _ = clip.load(sd, compute_dtype=dtype, max_batch=128, lib=_lib.load_lab())
+    direct.visual.set_option('patch_direct', 2)
+    prod, _ = clip.load(sd, compute_dtype=dtype, max_batch=4)
+    prod.encode_image(synthetic_images(1, seed=1).to(cuda))
+    with pytest.raises(_lib.OakeError):
+        prod.visual.set_option('patch_direct', 2)
     via_im2col, _ = clip.load(sd, compute_dtype=dtype, max_batch=128)
     via_im2col.visual.set_option('patch_direct', 0)
     for n in (128, 45, 300, 1):

@@ -14,6 +14,7 @@ from oadp_amd import _lib
 pytestmark = pytest.mark.gpu
 
 DT = {torch.float16: _lib.OAKE_F16, torch.bfloat16: _lib.OAKE_BF16}
+PROD_GEMM = (-1, 0, 4, 5)  # tile configurations of the production library; the others live in liboake_hip_lab.so
 
 
 def _stream():
@@ -29,8 +30,9 @@ def test_gemm(lib, cuda, dtype, m, n, k):
 
 @pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 132, 3072), (12800, 768, 128)])
-def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
+def test_gemm_tile_configs(lib, lab, cuda, variant, m, n, k):
     """Every tile configuration (csrc/gemm.hip) on ragged M/N edges."""
+    lib = lib if variant in PROD_GEMM else lab
     lib.oake_debug_set_gemm_variant(variant)
     try:
         _gemm_case(lib, cuda, torch.float16, m, n, k)
@@ -43,8 +45,9 @@ def test_gemm_tile_configs(lib, cuda, variant, m, n, k):
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 136, 512),
                                    (12800, 3072, 128)])
-def test_gemm_16bit_epilogues(lib, cuda, variant, gelu, dtype, m, n, k):
+def test_gemm_16bit_epilogues(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     """QKV / c_fc epilogues: bias (+QuickGELU) and the paired-column 16-byte stores."""
+    lib = lib if variant in PROD_GEMM else lab
     g = torch.Generator(device='cpu').manual_seed(m + n + k + gelu)
     a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
     w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(dtype).to(cuda)
@@ -70,9 +73,10 @@ def test_gemm_16bit_epilogues(lib, cuda, variant, gelu, dtype, m, n, k):
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (50, 2304, 768), (333, 136, 512),
                                    (12800, 1024, 256)])
-def test_gemm_layernorm_folded(lib, cuda, variant, gelu, dtype, m, n, k):
+def test_gemm_layernorm_folded(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     """LayerNorm folded into the consuming GEMM (16-bit residual stream): gamma in W, beta in the
     bias, per-row (rstd, -mean*rstd) applied in the epilogue == GEMM(LayerNorm(x)) in fp32."""
+    lib = lib if variant in PROD_GEMM else lab
     g = torch.Generator(device='cpu').manual_seed(m + n + k + gelu)
     x = torch.randn(m, k, generator=g) * 1.5 + 0.3
     x[:, 5] *= 12.0          # CLIP's residual stream has a few large-magnitude channels
@@ -102,12 +106,13 @@ def test_gemm_layernorm_folded(lib, cuda, variant, gelu, dtype, m, n, k):
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (2250, 768, 3072), (12800, 512, 256),
                                    (333, 136, 512), (50, 768, 768), (41000, 768, 192), (25600, 768, 768)])
-def test_gemm_residual_epilogue(lib, cuda, dtype, m, n, k, variant):
+def test_gemm_residual_epilogue(lib, lab, cuda, dtype, m, n, k, variant):
     """x += A W^T + b in the 16-bit residual stream (out_proj / c_proj), ragged tiles included, plus the
     per-slice row sums the persistent kernel leaves for the next GEMM's LayerNorm.  The last two shapes give
     every persistent block several tiles with different bias blocks (771 / 480 tiles on 256 CUs; K = 192 is
     the shortest K loop the kernel takes): the staging of a tile's epilogue constants must not overtake the
     previous tile's epilogue."""
+    lib = lib if variant in PROD_GEMM else lab
     g = torch.Generator(device='cpu').manual_seed(m + n + k)
     a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
     w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(dtype).to(cuda)
@@ -183,7 +188,8 @@ def _attention_ref(qkv, n, l, heads):
                                        (64, 50, 12), (7, 33, 5),
                                        # a last chunk of 49..63 keys: four key tiles, the last one partly valid
                                        (1, 114, 2), (4, 182, 10), (2, 253, 9), (1, 127, 5), (3, 113, 3)])
-def test_attention(lib, cuda, dtype, n, l, heads, use_tr):
+def test_attention(lib, lab, cuda, dtype, n, l, heads, use_tr):
+    lib = lib if use_tr == 31 else lab
     g = torch.Generator(device='cpu').manual_seed(n * 100 + l + heads)
     qkv = torch.randn(n * l, 3 * heads * 64, generator=g)
     qkv[:, :heads * 64] *= 0.35  # pre-scaled q: scores ~ N(0, 2.8^2): a peaky softmax
@@ -267,3 +273,20 @@ def test_attn_out_refuses_other_geometries(lib, cuda):
                                    _lib.OAKE_F16, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
     assert lib.oake_debug_attn_out(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 50, 8,
                                    _lib.OAKE_F16, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+
+
+def test_production_library_refuses_lab_variants(lib, lab):
+    """the product carries only what its own selection can return; the experiments are in the
+    lab build, and both say which they are."""
+    assert lib.oake_debug_lab_build() == 0 and lab.oake_debug_lab_build() == 1
+    for v in range(-1, 12):
+        want = _lib.OAKE_OK if v in PROD_GEMM else _lib.OAKE_ERR_UNSUPPORTED
+        assert lib.oake_debug_set_gemm_variant(v) == want, v
+        assert lab.oake_debug_set_gemm_variant(v) == _lib.OAKE_OK
+    assert lib.oake_debug_set_gemm_variant(12) == lab.oake_debug_set_gemm_variant(12) == _lib.OAKE_ERR_UNSUPPORTED
+    lib.oake_debug_set_gemm_variant(-1)
+    lab.oake_debug_set_gemm_variant(-1)
+    for v in (0, 7, 30, 63, 95, 128, -1):
+        assert lib.oake_debug_set_attention_variant(v) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lib.oake_debug_set_attention_variant(31) == _lib.OAKE_OK
+    assert lab.oake_debug_set_attention_variant(95) == _lib.OAKE_OK and lab.oake_debug_set_attention_variant(31) == _lib.OAKE_OK

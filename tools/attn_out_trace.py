@@ -12,7 +12,7 @@ from oadp_amd import _lib  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-lib = _lib.load()
+lib = _lib.load_lab()  # the build that carries every variant
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
 c = 768

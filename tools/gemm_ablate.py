@@ -10,7 +10,7 @@ import ctypes as C, sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oadp_amd import _lib
-lib = _lib.load()
+lib = _lib.load_lab()  # the build that carries every variant
 dev = torch.device('cuda:0')
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '4,8').split(',')]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5

@@ -4,7 +4,7 @@ import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oadp_amd import _lib
-lib = _lib.load()
+lib = _lib.load_lab()  # the build that carries every variant
 dev = torch.device('cuda:0')
 m, n, k = (int(v) for v in sys.argv[1:4])
 mode = sys.argv[4] if len(sys.argv) > 4 else 'bias'

@@ -6,7 +6,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oadp_amd import _lib
-lib = _lib.load()
+lib = _lib.load_lab()  # the build that carries every variant
 dev = torch.device('cuda:0')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0

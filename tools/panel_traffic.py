@@ -13,7 +13,7 @@ if sys.argv[1] == 'run':
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     from oadp_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_lab()  # the build that carries every variant
     dev = torch.device('cuda:0')
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for name, m, n, k, gelu in SHAPES:

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oadp_amd import _lib
 
-lib = _lib.load()
+lib = _lib.load_lab()  # the build that carries every variant (measurement epilogues)
 dev = torch.device('cuda:0')
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
