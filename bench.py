@@ -819,7 +819,7 @@ def main() -> int:
     if (rank == 0 and line is not None and headline_defaults and world == 1 and not DRY_PLUMBING
             and not args.no_modes and not args.no_profile):
         modes = {}
-        for mode, steps in (('blocks', 10), ('objects', 4)):
+        for mode, steps in (('blocks', 30), ('objects', 6)):
             t0 = time.perf_counter()
             sub_args = argparse.Namespace(**vars(args))
             sub_args.mode, sub_args.batch, sub_args.max_batch = mode, None, None

@@ -29,12 +29,8 @@ import numpy as np
 import torch
 
 from ..oake.objects import indices_min_wh
+from ..packfile import ALIGN as _ALIGN, DTYPES as _DTYPES, MAGIC as _MAGIC, fields as _fields
 from ..store import Store
-
-_MAGIC = 'oake-pack-1'
-_ALIGN = 64
-_DTYPES = {torch.float16: 'float16', torch.float32: 'float32', torch.float64: 'float64',
-           torch.int64: 'int64', torch.int32: 'int32', torch.uint8: 'uint8', torch.bool: 'bool'}
 
 
 class PthAccessLayer(Mapping):
@@ -54,17 +50,6 @@ class PthAccessLayer(Mapping):
 
     def __len__(self) -> int:
         return sum(1 for _ in self._dir.glob('*.pth'))
-
-
-def _fields(value: Any) -> list[tuple[str, torch.Tensor]]:
-    """A feature file holds a tensor (globals) or a flat dict of tensors (blocks, objects)."""
-    if isinstance(value, torch.Tensor):
-        return [('', value)]
-    if isinstance(value, dict) and all(isinstance(v, torch.Tensor) for v in value.values()):
-        if '' in value:
-            raise ValueError('empty field name')
-        return list(value.items())
-    raise TypeError(f'cannot pack {type(value).__name__}: expected a tensor or a dict of tensors')
 
 
 def pack(data_root: str, task_name: str, out: str | None = None) -> pathlib.Path:
@@ -104,25 +89,35 @@ class PackAccessLayer(Mapping):
     for callers that write into what they load."""
 
     def __init__(self, data_root: str, task_name: str = '', copy: bool = False, **_: Any) -> None:
-        self._blob = pathlib.Path(data_root) / f'{task_name}.pack'
-        meta = json.loads(self._blob.with_name(self._blob.name + '.json').read_text())
-        if meta.get('magic') != _MAGIC:
-            raise ValueError(f'{self._blob}: not an OAKE feature pack')
-        if self._blob.stat().st_size != meta['bytes']:
-            raise ValueError(f'{self._blob}: size does not match its index (truncated pack?)')
-        self._index: dict[str, list] = meta['index']
+        # one blob (`pack()`, or a one-rank sweep with writer='pack') or the shards of a multi-rank sweep
+        # (`<task_name>.r<rank>of<world>.pack`): the index maps a key to (shard, fields)
+        root = pathlib.Path(data_root)
+        blobs = [p for p in [root / f'{task_name}.pack'] if p.exists()] + sorted(root.glob(f'{task_name}.r*of*.pack'))
+        if not blobs:
+            raise FileNotFoundError(root / f'{task_name}.pack')
+        self._blobs = blobs
+        self._index: dict[str, tuple[int, list]] = {}
+        for i, blob in enumerate(blobs):
+            meta = json.loads(blob.with_name(blob.name + '.json').read_text())
+            if meta.get('magic') != _MAGIC:
+                raise ValueError(f'{blob}: not an OAKE feature pack')
+            if blob.stat().st_size < meta['bytes']:  # (longer is fine: a killed writer's tail behind the index)
+                raise ValueError(f'{blob}: size does not match its index (truncated pack?)')
+            for key, entry in meta['index'].items():
+                self._index.setdefault(key, (i, entry))
         self._copy = copy
-        self._map: np.memmap | None = None
+        self._maps: list[np.memmap | None] = [None] * len(blobs)
 
     def __getstate__(self) -> dict:
-        return dict(self.__dict__, _map=None)
+        return dict(self.__dict__, _maps=[None] * len(self._blobs))
 
-    def _view(self, dtype: str, shape: list[int], offset: int) -> torch.Tensor:
-        if self._map is None:
-            self._map = np.memmap(self._blob, dtype=np.uint8, mode='r') if self._blob.stat().st_size \
+    def _view(self, shard: int, dtype: str, shape: list[int], offset: int) -> torch.Tensor:
+        if self._maps[shard] is None:
+            blob = self._blobs[shard]
+            self._maps[shard] = np.memmap(blob, dtype=np.uint8, mode='r') if blob.stat().st_size \
                 else np.zeros(0, np.uint8)
         n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-        a = self._map[offset:offset + n].view(dtype).reshape(shape)
+        a = self._maps[shard][offset:offset + n].view(dtype).reshape(shape)
         if self._copy:
             return torch.from_numpy(np.array(a))
         import warnings
@@ -131,10 +126,10 @@ class PackAccessLayer(Mapping):
             return torch.from_numpy(a)
 
     def __getitem__(self, key: str) -> Any:
-        entry = self._index[key]
+        shard, entry = self._index[key]
         if len(entry) == 1 and entry[0][0] == '':
-            return self._view(*entry[0][1:])
-        return {name: self._view(dtype, shape, offset) for name, dtype, shape, offset in entry}
+            return self._view(shard, *entry[0][1:])
+        return {name: self._view(shard, dtype, shape, offset) for name, dtype, shape, offset in entry}
 
     def __iter__(self) -> Iterator[str]:
         return iter(self._index)

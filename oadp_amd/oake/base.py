@@ -27,6 +27,7 @@ import torch.utils.data.distributed
 from ..config import Config, parse_override
 from ..store import Store, get_local_rank, get_rank, get_world_size, parse_shard, pin_cpus, shard_device_index
 from . import fastsave
+from ..packfile import PackWriter, blob_path
 
 
 class Batch(Protocol):
@@ -103,6 +104,9 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
         self._device_decode = device_decode
         self._output_dir = pathlib.Path(output_dir)
         self._output_dir.mkdir(parents=True, exist_ok=True)
+        # keys ("<image_id:012d>") a direct pack writer already holds (BaseValidator(writer='pack')): skipped like
+        # images whose .pth file exists
+        self._done: set[str] = set()
 
     @property
     def transforms(self):
@@ -133,6 +137,8 @@ class BaseDataset(torch.utils.data.Dataset, ABC, Generic[T]):
         # reference oadp/oake/base.py:42-54 (resume by skipping; auto_fix re-verifies the file)
         id_ = self.ids[index]
         output = self._output_dir / f'{id_:012d}.pth'
+        if output.stem in self._done:
+            return None
         if output.exists():
             if not self._auto_fix:
                 return None
@@ -357,7 +363,7 @@ class BaseValidator(ABC, Generic[T]):
     def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
                  batch_size: int = 256, device: torch.device | str | None = None,
                  writer_threads: int = 4, decode_threads: int = 16, prefetch: int = 512,
-                 streams: int = 2, host_threads: int = 8, **kwargs) -> None:
+                 streams: int = 2, host_threads: int = 8, writer: str = 'pth', **kwargs) -> None:
         if kwargs:  # a misspelled option must not vanish silently
             raise TypeError(f'{type(self).__name__}: unknown option(s) {sorted(kwargs)}')
         self.name = name
@@ -369,6 +375,12 @@ class BaseValidator(ABC, Generic[T]):
         self._device = torch.device(device)
         self.counters = Counters()
         self._writer_threads = writer_threads
+        # 'pth' (default): one <image_id:012d>.pth per image, the reference's contract [REF oadp/oake/base.py:44,112].
+        # 'pack': the same payloads appended to ONE memory-mappable blob per split (and rank) + a JSON index, read by
+        # oadp_amd.dp.PackAccessLayer (oadp_amd/packfile.py) — no per-image files at all
+        if writer not in ('pth', 'pack'):
+            raise ValueError(f"writer must be 'pth' or 'pack', got {writer!r}")
+        self._writer_kind = writer
         self._decode_threads = decode_threads
         self._prefetch = prefetch
         # torch's intra-op pool for the sweep: the host side of a flush is hundreds of tiny tensor ops per
@@ -541,7 +553,13 @@ class BaseValidator(ABC, Generic[T]):
         torch_threads = torch.get_num_threads()
         if 0 < self._host_threads < torch_threads:  # (before the worker threads run their first tensor op)
             torch.set_num_threads(self._host_threads)
-        self._writer = AsyncWriter(self._writer_threads)
+        if self._writer_kind == 'pack':
+            ds = self._dataloader.dataset
+            shard = parse_shard() or (get_rank(), get_world_size())
+            self._writer = PackWriter(blob_path(ds._output_dir, *shard))
+            ds._done = self._writer.keys  # resume: what the blob already holds
+        else:
+            self._writer = AsyncWriter(self._writer_threads)
         try:
             self._run_loop(pending, crops)
         finally:

@@ -2,6 +2,7 @@
 per-image .pth files hold, and LoadCLIPFeatures (oadp/dp/datasets.py:137-214) gives the same results
 through either."""
 import json
+import pathlib
 import pickle
 
 import numpy as np
@@ -169,3 +170,101 @@ def test_val_split_switch(oake_root, monkeypatch):
     step = LoadCLIPFeatures(default=dict(task_name='train2017', type='PthAccessLayer'),
                             globals_=dict(data_root=str(root / 'globals')))
     assert torch.equal(step(dict(img_info=dict(id=ids[0]), bbox_fields=[]))['clip_global'], torch.ones(512).half())
+
+
+# ---- the validators' direct pack writer (second half) -------------------
+def _validators(coco, root, writer, shard=None, monkeypatch=None):
+    from oadp_amd.config import Config
+    from oadp_amd.oake import blocks, globals as globals_, objects
+    from . import _synth
+    if monkeypatch is not None:
+        if shard:
+            monkeypatch.setenv('OAKE_SHARD', shard)
+        else:
+            monkeypatch.delenv('OAKE_SHARD', raising=False)
+        monkeypatch.setenv('OAKE_CPU_AFFINITY', '0')
+
+    def dl(mode, **extra):
+        return Config(dataset=dict(root=coco['root'], annFile=coco['annFile'], output_dir=str(root / mode / 'train2017'),
+                                   transform=_synth.preprocess(), **extra), num_workers=0)
+    counts = {}
+    counts['globals'] = globals_.Validator('g', _synth.OracleModel(), dataloader=dl('globals'), batch_size=4,
+                                           device='cpu', writer=writer).run().images
+    counts['blocks'] = blocks.Validator('b', _synth.OracleModel(), dataloader=dl('blocks'), batch_size=8,
+                                        device='cpu', writer=writer).run().images
+    model = _synth.OracleModel()
+    model.visual.objects_mode()
+    counts['objects'] = objects.Validator(
+        'o', model, dataloader=dl('objects', type='COCODataset', proposal_file=coco['proposal_file'], proposal_sorted=True),
+        mini_batch_size=7, batch_size=16, device='cpu', writer=writer).run().images
+    return counts
+
+
+def test_validators_write_packs_directly(tmp_path, monkeypatch):
+    """writer='pack': the three validators append every flush to one blob + index per tree — no per-image files —
+    and PackAccessLayer returns, key for key and bit for bit, what PthAccessLayer returns for the default writer."""
+    from . import _synth
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    coco = _synth.make_coco(tmp_path / 'coco', [(300, 260), (224, 224), (500, 375), (250, 340), (100, 90), (640, 480)],
+                            proposals_per_image=15)
+    pth_root, pack_root = tmp_path / 'pth', tmp_path / 'pack'
+    n = len(coco['ids'])
+    assert _validators(coco, pth_root, 'pth', monkeypatch=monkeypatch) == dict(globals=n, blocks=n, objects=n)
+    assert _validators(coco, pack_root, 'pack', monkeypatch=monkeypatch) == dict(globals=n, blocks=n, objects=n)
+    for mode in ('globals', 'blocks', 'objects'):
+        assert not list((pack_root / mode / 'train2017').glob('*.pth'))            # no small files
+        assert (pack_root / mode / 'train2017.pack').exists() and (pack_root / mode / 'train2017.pack.json').exists()
+        a, b = PthAccessLayer(str(pth_root / mode), 'train2017'), PackAccessLayer(str(pack_root / mode), 'train2017')
+        assert sorted(a) == sorted(b) == [f'{i:012d}' for i in coco['ids']]
+        for key in a:
+            _same(a[key], b[key])
+    # resume: a second run finds every key in the blob and encodes nothing; the blob is unchanged
+    before = (pack_root / 'blocks' / 'train2017.pack').read_bytes()
+    assert _validators(coco, pack_root, 'pack', monkeypatch=monkeypatch) == dict(globals=0, blocks=0, objects=0)
+    assert (pack_root / 'blocks' / 'train2017.pack').read_bytes() == before
+    # ... and LoadCLIPFeatures over the direct packs == over the .pth trees
+    cfg = lambda root: dict(globals_=dict(data_root=str(root / 'globals')), blocks=dict(data_root=str(root / 'blocks')),
+                            objects=dict(data_root=str(root / 'objects')))
+    s_pth = LoadCLIPFeatures(default=dict(task_name='train2017', type='PthAccessLayer'), **cfg(pth_root))
+    s_pack = LoadCLIPFeatures(default=dict(task_name='train2017', type='PackAccessLayer'), **cfg(pack_root))
+    for id_ in coco['ids']:
+        x, y = s_pth(_sample(id_)), s_pack(_sample(id_))
+        assert list(x) == list(y)
+        for k in x:
+            if isinstance(x[k], torch.Tensor):
+                assert torch.equal(x[k], y[k])
+            elif isinstance(x[k], np.ndarray):
+                assert np.array_equal(x[k], y[k])
+
+
+def test_sharded_packs_and_a_killed_writer(tmp_path, monkeypatch):
+    """Two shards (OAKE_SHARD=r/2) write train2017.r0of2.pack / .r1of2.pack; the access layer reads their union.  A
+    writer killed between index checkpoints leaves a tail behind the index: ignored by readers, truncated on resume."""
+    from oadp_amd.packfile import PackWriter, blob_path
+    from . import _synth
+    monkeypatch.delenv('DRY_RUN', raising=False)
+    coco = _synth.make_coco(tmp_path / 'coco', [(300, 260), (224, 224), (250, 340), (100, 90), (320, 240)])
+    root = tmp_path / 'oake'
+    total = 0
+    for r in range(2):
+        total += _validators(coco, root, 'pack', shard=f'{r}/2', monkeypatch=monkeypatch)['globals']
+    assert total in (len(coco['ids']), len(coco['ids']) + 1)  # (the sampler pads 5 images to 6 by wrap-around)
+    assert sorted(p.name for p in (root / 'globals').glob('*.pack')) == ['train2017.r0of2.pack', 'train2017.r1of2.pack']
+    layer = PackAccessLayer(str(root / 'globals'), 'train2017')
+    assert sorted(layer) == [f'{i:012d}' for i in coco['ids']]
+    monkeypatch.delenv('OAKE_SHARD')
+    blob = blob_path(tmp_path / 'k' / 'train2017')
+    w = PackWriter(blob, checkpoint=2)
+    for i in range(5):  # index checkpoints after keys 2 and 4; key 5 stays behind the index
+        w.submit(torch.full((3,), float(i)).half(), pathlib.Path(f'{i:012d}.pth'))
+    w._f.flush()  # (killed here: no close)
+    r = PackAccessLayer(str(tmp_path / 'k'), 'train2017')
+    assert sorted(r) == [f'{i:012d}' for i in range(4)] and torch.equal(r['000000000003'], torch.full((3,), 3.0).half())
+    w2 = PackWriter(blob)  # resume: the orphaned tail goes, the four indexed keys stay
+    assert w2.keys == {f'{i:012d}' for i in range(4)} and blob.stat().st_size == w2._offset
+    w2.submit(torch.full((3,), 9.0).half(), pathlib.Path('000000000009.pth'))
+    w2.submit(torch.full((3,), 1.0).half(), pathlib.Path('000000000001.pth'))  # a duplicate key is dropped
+    w2.close()
+    r = PackAccessLayer(str(tmp_path / 'k'), 'train2017')
+    assert len(r) == 5 and torch.equal(r['000000000009'], torch.full((3,), 9.0).half())
+    assert torch.equal(r['000000000001'], torch.full((3,), 1.0).half())
