@@ -5,8 +5,12 @@ Reference flow (vild.py:54-72): for each of the 74 templates, format every categ
 embeddings per category; save ``dict(embeddings=[K, 512], names=[K])`` to data/prompts/vild.pth.
 Here ``encode_text`` is ``oake_encode_text`` (csrc: the vision tower's kernels with a causal mask).
 
-Not shipped with this repo: the category lists (``oadp.base.coco / lvis``: pass ``categories``) and the
-BPE vocabulary of CLIP's tokenizer (pass ``encode``: text -> list of token ids without SOT/EOT).
+``python -m oadp_amd.prompts.vild`` is the reference's entry point [REF oadp/prompts/vild.py:54-76].  Two inputs are
+assets this repo does not carry and takes as paths: the category NAMES — read from the datasets' own annotation
+files (``categories[].name`` of the OV-COCO / LVIS v1 JSONs the reference trains on: the same strings as
+``oadp.base.coco.all_ + lvis.all_``) or from a one-name-per-line text file — and the BPE vocabulary of CLIP's
+tokenizer (``bpe_simple_vocab_16e6.txt.gz``; ``oadp_amd/prompts/bpe.py`` restates the algorithm).  As a library:
+pass ``categories`` and ``encode`` (text -> token ids without SOT / EOT).
 """
 from __future__ import annotations
 
@@ -78,3 +82,40 @@ def main(categories: Sequence[str], encode: Callable[[str], Sequence[int]], *, m
     path.parent.mkdir(parents=True, exist_ok=True)
     torch.save(state, path)
     return state
+
+
+def read_categories(paths: Sequence[str]) -> list[str]:
+    """Category names of COCO / LVIS-format annotation files (``categories[].name``) and / or text files with one
+    name per line; the union, as the reference's ``sorted(set(coco.all_ + lvis.all_))``."""
+    import json
+    names: set[str] = set()
+    for p in paths:
+        text = pathlib.Path(p).read_text()
+        if p.endswith('.json'):
+            names.update(c['name'] for c in json.loads(text)['categories'])
+        else:
+            names.update(line.strip() for line in text.splitlines() if line.strip())
+    return sorted(names)
+
+
+def cli(argv: Sequence[str] | None = None) -> None:
+    import argparse
+    from .bpe import Tokenizer
+    ap = argparse.ArgumentParser(description='ViLD prompt-ensemble text embeddings of the category names '
+                                             '(data/prompts/vild.pth of the reference)')
+    ap.add_argument('--categories-from', nargs='+',
+                    default=['data/coco/annotations/instances_val2017.65.min.json',
+                             'data/lvis_v1/annotations/lvis_v1_val.json'],
+                    help='annotation JSONs (categories[].name) and / or one-name-per-line text files')
+    ap.add_argument('--bpe', default='pretrained/clip/bpe_simple_vocab_16e6.txt.gz', help="CLIP's BPE vocabulary file")
+    ap.add_argument('--output', default='data/prompts/vild.pth')
+    ap.add_argument('--dtype', choices=['float32', 'float16'], default='float32',
+                    help='float16: the file the reference writes when its CLIP runs on a GPU')
+    a = ap.parse_args(argv)
+    state = main(read_categories(a.categories_from), Tokenizer(a.bpe).encode, output=a.output,
+                 dtype=getattr(torch, a.dtype))
+    print(f'{a.output}: {len(state["names"])} categories x {state["embeddings"].shape[1]}')
+
+
+if __name__ == '__main__':
+    cli()

@@ -499,3 +499,45 @@ def test_shard_parsing_device_choice_and_cpu_slices():
     parts = [cpu_slice(i, 8, cpus) for i in range(8)]
     assert all(len(p) == 32 for p in parts) and sorted(sum(parts, [])) == cpus
     assert cpu_slice(2, 3, list(range(10))) == [6, 7, 8, 9] and cpu_slice(0, 16, list(range(8))) == list(range(8))
+
+
+def test_bpe_tokenizer_matches_an_independent_implementation(tmp_path):
+    """oadp_amd/prompts/bpe.py against HuggingFace's CLIPTokenizer (slow, pure Python) on a SYNTHETIC merge table —
+    CLIP's real vocabulary is not in this image; the algorithm (byte mapping, '</w>', greedy merges by rank, id
+    layout) is what is pinned.  Plus the category reader of `python -m oadp_amd.prompts.vild`."""
+    import json
+    import random
+    from transformers import CLIPTokenizer
+    from oadp_amd.prompts import bpe, vild
+    rnd = random.Random(0)
+    b2u = bpe.bytes_to_unicode()
+    letters = [b2u[b] for b in b'abcdefghijklmnopqrstuvwxyz']
+    merges, have = [], set()
+    symbols = set(letters) | {c + '</w>' for c in letters}
+    while len(merges) < 300:  # random merges over symbols that exist so far (a valid BPE table)
+        a, b = rnd.choice(sorted(symbols)), rnd.choice(sorted(symbols))
+        if a.endswith('</w>') or (a, b) in have:
+            continue
+        have.add((a, b))
+        merges.append((a, b))
+        symbols.add(a + b)
+    vocab_file = tmp_path / 'bpe_vocab.txt'
+    filler = []  # (a short table: the special tokens then sit at 512 + 300 instead of CLIP's 49406 / 49407)
+    vocab_file.write_text('#version: 0.2\n' + '\n'.join(' '.join(m) for m in merges + filler) + '\n')
+    tok = bpe.Tokenizer(vocab_file)
+    assert tok.encoder['<|startoftext|>'] == 512 + len(merges) and tok.encoder['<|endoftext|>'] == 513 + len(merges)
+    assert 512 + bpe.N_MERGES == vild.SOT and vild.EOT == vild.SOT + 1  # ... and with the full table at CLIP's ids
+    # the independent implementation, fed the same table
+    hf_vocab = tmp_path / 'vocab.json'
+    hf_vocab.write_text(json.dumps(tok.encoder))
+    hf_merges = tmp_path / 'merges.txt'
+    hf_merges.write_text('#version: 0.2\n' + '\n'.join(' '.join(m) for m in merges + filler) + '\n')
+    hf = CLIPTokenizer(str(hf_vocab), str(hf_merges))
+    words = [''.join(rnd.choice('abcdefghijklmnopqrstuvwxyz') for _ in range(rnd.randint(1, 9))) for _ in range(300)]
+    for text in words + ['a photo of a ' + w for w in words[:40]] + ['There is the small traffic_light in the scene',
+                                                                     "it's 2 cats, and   one dog!"]:
+        assert tok.encode(text) == hf.encode(text, add_special_tokens=False), text
+    # categories from annotation files / text files, the reference's sorted(set(...))
+    (tmp_path / 'a.json').write_text(json.dumps(dict(categories=[dict(id=1, name='person'), dict(id=2, name='traffic_light')])))
+    (tmp_path / 'b.txt').write_text('aerosol_can\nperson\n\n')
+    assert vild.read_categories([str(tmp_path / 'a.json'), str(tmp_path / 'b.txt')]) == ['aerosol_can', 'person', 'traffic_light']
