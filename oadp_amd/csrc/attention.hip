@@ -26,6 +26,9 @@
 #ifndef OAKE_LAB
 #define OAKE_LAB 0
 #endif
+#ifndef OAKE_ATTN_SETPRIO
+#define OAKE_ATTN_SETPRIO 0
+#endif
 
 namespace oake {
 
@@ -654,6 +657,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     if (fast) {
       const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 sacc[4][MT];
+#if OAKE_ATTN_SETPRIO  // (measurement switch: issue priority for the MFMA clusters, the guide's per-cluster s_setprio)
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const vec8 kf0 = *reinterpret_cast<const vec8*>(ks + (kt * 16 + fr) * kVStride + g * 8);
@@ -664,6 +670,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
           sacc[kt][mt] = T16<T>::mfma(kf1, qf[mt][1], sacc[kt][mt]);
         }
       }
+#if OAKE_ATTN_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       vec8 pf[MT][2];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -703,6 +712,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
           pf[mt][ksx] = p8;
         }
       }
+#if OAKE_ATTN_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int ksx = 0; ksx < 2; ++ksx) {
 #pragma unroll
@@ -721,6 +733,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
           for (int mt = 0; mt < MT; ++mt) oacc[dt][mt] = T16<T>::mfma(vf, pf[mt][ksx], oacc[dt][mt]);
         }
       }
+#if OAKE_ATTN_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     } else if (!skip) {
       f32x4 sacc[4][MT];
 #pragma unroll

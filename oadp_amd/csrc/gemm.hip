@@ -1119,11 +1119,22 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     _Pragma("unroll") for (int i = 0; i < NI; ++i)                                          \
         bf[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + (koff_)); \
   } while (0)
+// (measurement switch -DOAKE_GEMM_SETPRIO=1: the wave raises its issue priority for its MFMA phase — the guide's
+// per-cluster s_setprio; round 1 had only tried static priorities, +-0.5 %)
+#ifndef OAKE_GEMM_SETPRIO
+#define OAKE_GEMM_SETPRIO 0
+#endif
+#define OAKE_PRIO(n_)                                             \
+  do {                                                            \
+    if (OAKE_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(n_);        \
+  } while (0)
 #define OAKE_MFMA_BLOCK()                                                                   \
   do {                                                                                      \
+    OAKE_PRIO(1);                                                                           \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                       \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                   \
             acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);                        \
+    if (!PH2) OAKE_PRIO(0);                                                                 \
   } while (0)
   // (after the epilogue, not while it consumes the rows: zeroed early, the accumulators would stay
   // live — as zeros — next to the packed tile and the epilogue constants)
@@ -1183,6 +1194,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf1[ni], af1[mi], acc[mi][ni]);
+      OAKE_PRIO(0);
     } else {
     OAKE_LOAD_FRAGS(c_buf, koff0);
     OAKE_LGKM0();
@@ -1284,6 +1296,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 #undef OAKE_STORE_PEND
 #undef OAKE_LOAD_FRAGS
 #undef OAKE_MFMA_BLOCK
+#undef OAKE_PRIO
 #undef OAKE_LGKM0
 #undef OAKE_PIN
 #undef OAKE_BAR
