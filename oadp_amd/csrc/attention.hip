@@ -657,7 +657,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     if (fast) {
       const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 sacc[4][MT];
-#if OAKE_ATTN_SETPRIO  // (measurement switch: issue priority for the MFMA clusters, the guide's per-cluster s_setprio)
+#if OAKE_ATTN_SETPRIO  // (measurement switch: issue priority for the MFMA clusters; objects 83.8 vs 83.6 images/s and
+                       // 12 bytes of scratch at the kernel's 160 registers, profiles/r04/ab_session_setprio_objects.log: off)
       __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll

@@ -1119,10 +1119,12 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     _Pragma("unroll") for (int i = 0; i < NI; ++i)                                          \
         bf[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + (koff_)); \
   } while (0)
-// (measurement switch -DOAKE_GEMM_SETPRIO=1: the wave raises its issue priority for its MFMA phase — the guide's
-// per-cluster s_setprio; round 1 had only tried static priorities, +-0.5 %)
+// A compute wave raises its issue priority for its MFMA phase (s_setprio 1 .. 0 around the cluster: while it issues
+// MFMAs its SIMD's other compute wave reads fragments and the DMA wave issues pieces).  Round 1 had only tried static
+// priorities (+-0.5 %); per phase: 112.88 vs 112.59 k images/s, every round above every base round, one lane equal
+// (profiles/r04/ab_session_setprio_globals.log), objects 83.7 vs 83.6.  -DOAKE_GEMM_SETPRIO=0: without.
 #ifndef OAKE_GEMM_SETPRIO
-#define OAKE_GEMM_SETPRIO 0
+#define OAKE_GEMM_SETPRIO 1
 #endif
 #define OAKE_PRIO(n_)                                             \
   do {                                                            \
