@@ -956,7 +956,9 @@ int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, 
   if ((rc = grow(h, s, &h->rs_jobs, &h->rs_jobs_cap, jobs.size() * sizeof(ResampleJob)))) return rc;
   if ((rc = grow(h, s, &h->rs_coef, &h->rs_coef_cap, (size_t)coef * 4))) return rc;
   if ((rc = grow(h, s, &h->rs_bounds, &h->rs_bounds_cap, (size_t)bnd * 4))) return rc;
-  if ((rc = grow(h, s, &h->rs_temp, &h->rs_temp_cap, (size_t)temp))) return rc;
+  // (+ 16: resample_v4_kernel's 16-byte loads start at the 4-byte-aligned address below a 12-byte window and may
+  // read up to 4 bytes past it — past the last job's temp image when the window is its last 12 bytes)
+  if ((rc = grow(h, s, &h->rs_temp, &h->rs_temp_cap, (size_t)temp + 16))) return rc;
   if ((rc = upload_async(h, s, jobs.data(), jobs.size() * sizeof(ResampleJob), h->rs_jobs))) return rc;
   double bytes = (double)temp * 2;
   if (out_dtype == DT_U8)

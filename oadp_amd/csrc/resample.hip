@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ResampleJob* __re
 // 4-byte-aligned address + v_alignbyte instead of twelve byte loads, and one 8-byte (f16) / 16-byte (f32) store per
 // colour plane instead of four scalar ones.  Same integer arithmetic in the same order: bit-identical.  Threads
 // whose four pixels are not all inside the resized image (crop windows hanging over it) and transposed jobs take
-// the per-pixel path.  (The load may touch up to 3 bytes past the 12 it needs: the scratch image is allocated with
-// slack, api.hip grow().)
+// the per-pixel path.  (The 16-byte load starts at the 4-byte-aligned address at or below the window: it may touch up to 4
+// bytes past the 12 it needs; run_resample asks for 16 bytes more than the temp images take, api.hip.)
 template <typename TOUT>
 __global__ __launch_bounds__(256) void resample_v4_kernel(const ResampleJob* __restrict__ jobs,
                                                           const int32_t* __restrict__ coef,
