@@ -568,7 +568,11 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
     # pass over one batch, but the kernels of step k+1 fill the start-up / tail bubbles of step k
     # (OAKE_BENCH_LANES=1: one stream, every kernel of a step strictly after the previous step's)
     n_lanes = args.lanes
-    lane_streams = [torch.cuda.Stream(dev) for _ in range(n_lanes)] if not DRY_PLUMBING else []
+    # (one set of lane streams per PROCESS: the HIP runtime multiplexes streams over 4 hardware queues, and a second
+    # pair created after the first run's streams — the `modes` sub-records — landed on ONE queue: two lanes, no
+    # overlap, blocks 3.83 k images/s where its own process gives 4.0 k; profiles/r04/README note, session s13)
+    lane_streams = [] if DRY_PLUMBING else ctx.setdefault(
+        ('lane_streams', n_lanes), [torch.cuda.Stream(dev) for _ in range(n_lanes)])
     # OAKE_BENCH_CU_SPLIT=<scheme> (two lanes): each lane's stream is restricted to one half of the compute units
     # (hipExtStreamCreateWithCUMask; oadp_amd/cumask.py) and its handle sizes its persistent grids to that half:
     # the two lanes' kernels then run side by side instead of taking turns on the whole chip
@@ -666,7 +670,10 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
             sync()
             one_lane_ms = (time.perf_counter() - t1) / n1 * 1e3
             one_lane = round(work.units / one_lane_ms * 1e3, 1)
-        roofline, kernels, timing = _kernel_profile(model, work, one_lane_ms, 5 if args.mode == 'globals' else 2)
+        # (globals: 40 steps = 0.1 s of stamped launches — a 5-step average moved by +-2.5 % from run to run against the
+        # rocprofv3 trace of the same process, profiles/r04/globals)
+        roofline, kernels, timing = _kernel_profile(model, work, one_lane_ms,
+                                                    {'globals': 40, 'blocks': 4}.get(args.mode, 2))
         # HBM bytes per launch cannot be sampled from inside this process: they come from separate
         # rocprofv3 --pmc passes over this same command (tools/pmc_traffic.py), committed under profiles/
         # together with the session they were measured in.  Reported only for the matching configuration
