@@ -93,7 +93,8 @@ typedef struct oake_config {
   int32_t mlp_dim;
   int32_t embed_dim;
   int32_t compute_dtype;
-  int32_t max_batch;      /* workspace is sized for this many crops per internal pass */
+  int32_t max_batch;      /* workspace is sized for this many crops per internal pass (the vision tower caps it at
+                             ~25 600 token rows per pass: OAKE_PASS_ROWS, csrc/api.hip) */
   int32_t residual_dtype; /* element type of the residual stream x: == compute_dtype (default; the
                              reference's GPU model keeps x in fp16 too) or OAKE_F32 */
 } oake_config;
@@ -302,8 +303,8 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *   OAKE_OPT_GEMM_PANEL         GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside),
  *                               n < 0 = M slabs of -n tiles (column-major inside).  Default 0.
  *   OAKE_OPT_ATTENTION_VARIANT  bit set of attention kernel forms (documented with
- *                               oake_debug_set_attention_variant, oake_hip_debug.h).  Default 31 — the only value the
- *                               production library accepts (OAKE_ERR_INVALID otherwise); the lab build takes 0..127.
+ *                               oake_debug_set_attention_variant, oake_hip_debug.h).  Default 159; the production
+ *                               library accepts 159 and 31 (OAKE_ERR_INVALID otherwise); the lab build takes 0..255.
  *   OAKE_OPT_PATCH_DIRECT       conv1 gathers its patch rows straight from a 16-bit NCHW input batch (no
  *                               im2col pass) where the geometry allows it.  0 = always im2col.  2 = also from an
  *                               FP32 batch (patch 32): the GEMM's DMA waves load, round and write the LDS image

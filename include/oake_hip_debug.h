@@ -41,6 +41,12 @@ OAKE_API int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_g
 /* Multi-head self-attention on packed qkv [n*l, 3*heads*64] (q pre-scaled), -> [n*l, heads*64]. */
 OAKE_API int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads,
                          int dtype16, void* stream);
+/* The same with the objects-mode object token fused in (oadp/oake/objects.py:232-247): qkv_y [n, 3*heads*64] holds
+ * one extra query / key / value per sequence; its keys are the sequence's rows 1..l-1 with the additive bias
+ * -100 * mask[n, l-1] (mask_dtype OAKE_F32 or OAKE_F16) plus its own key; d_out_y [n, heads*64].
+ * OAKE_ERR_UNSUPPORTED when the selected kernel form has no place for the token at this l. */
+OAKE_API int oake_debug_attention_objects(const void* d_qkv, const void* d_qkv_y, const void* d_mask, int mask_dtype,
+                                 void* d_out, void* d_out_y, int n, int l, int heads, int dtype16, void* stream);
 /* The fused form for sequences of at most 64 tokens (csrc/attn_out.hip; heads = 12 only, else
  * OAKE_ERR_UNSUPPORTED): x[n*l, heads*64] (16-bit, in place) += attention(qkv) * W^T + bias with W [heads*64,
  * heads*64] row-major 16-bit, and d_rowpart [n*l, 16, 2] fp32 receives (sum, sum of squares) of every 64-column
@@ -72,7 +78,9 @@ OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int ite
  * eight waves per (crop, head) reads K / V once (else two blocks of four read them twice; measured slower,
  * so not in the default), 64 = sequences of 65..208 keys: the whole K / V of a (crop, head) is brought into
  * LDS up front with LDS-DMA and the key loop runs without barriers or global accesses (measured equal, so not
- * in the default either).  Default 31. */
+ * in the default either), 128 = sequences of 193..208 keys without a causal mask (objects mode, 197): one block per
+ * (crop, head), the whole score matrix of a 32-query unit in registers, one-pass softmax (attention_head.inc).
+ * Default 159; the production library also accepts 31 (the cooperative kernel at 197 keys, for A/B runs). */
 OAKE_API int oake_debug_set_attention_variant(int variant);
 /* 1 in liboake_hip_lab.so (built with -DOAKE_LAB=1: the production kernels plus every tile configuration, kernel form
  * and measurement epilogue that lost its A/B), 0 in the production library, whose oake_debug_set_* / oake_set_option

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -411,6 +412,21 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
     h->kpatch = 3 * c.patch_size * c.patch_size;
   }
   h->layers.resize(c.layers);
+  if (!text) {
+    // Crops per internal pass: at most cfg.max_batch, and at most what keeps a pass at ~25 600 token rows — the size
+    // at which a pass's activations (x, qkv, att, hbuf: 12 KB per row) still turn over inside the 256-MB Infinity
+    // Cache between the kernel that writes them and the one that reads them.  Measured in one session
+    // (tools/mb_sweep.sh, profiles/r04/pass_rows_sweep.log): objects mode (L = 197) 25.4 / 26.0 / 26.2 k crops/s at
+    // 512 / 256 / 128 crops per pass, blocks mode (L = 50) 111.0 / 108.3 / 98.4 k at 512 / 256 / 128 and 108.5 /
+    // 105.9 at 1024 / 1728 (round 3) — both best at ~25 k rows.  OAKE_PASS_ROWS overrides the target (0: no limit).
+    long rows = 25600;
+    if (const char* e = std::getenv("OAKE_PASS_ROWS")) rows = std::atol(e);
+    if (rows > 0) {
+      long per = std::max<long>(32, rows / h->tokens / 32 * 32);
+      if (const char* e = std::getenv("OAKE_PASS_CROPS")) per = std::max<long>(1, std::atol(e));  // (experiments)
+      if (per < c.max_batch) h->cfg.max_batch = c.max_batch = (int)per;
+    }
+  }
 
   const size_t C = c.width, F = c.mlp_dim, E = c.embed_dim, L = h->tokens, B = c.max_batch;
   int rc = OAKE_OK;
@@ -1692,6 +1708,14 @@ int oake_debug_attention(const void* d_qkv, void* d_out, int n, int l, int heads
                               nullptr, nullptr, 0, nullptr, &t_debug_opts));
 }
 
+int oake_debug_attention_objects(const void* d_qkv, const void* d_qkv_y, const void* d_mask, int mask_dtype,
+                                 void* d_out, void* d_out_y, int n, int l, int heads, int dtype16, void* stream) {
+  if (!d_qkv || !d_qkv_y || !d_mask || !d_out || !d_out_y) return OAKE_ERR_INVALID;
+  if (!attention_fuses_object_token(l, &t_debug_opts)) return OAKE_ERR_UNSUPPORTED;
+  return dbg(launch_attention(dtype16, d_qkv, d_out, n, l, heads, 0, reinterpret_cast<hipStream_t>(stream), d_qkv_y,
+                              d_mask, mask_dtype, d_out_y, &t_debug_opts));
+}
+
 int oake_debug_attn_out(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x, float* d_rowpart,
                         int n, int l, int heads, int dtype16, void* stream) {
   return oake_debug_attn_out_trace(d_qkv, d_w, d_bias, d_x, d_rowpart, n, l, heads, dtype16, nullptr, 1, stream);
@@ -1754,7 +1778,7 @@ int oake_debug_set_gemm_trace(void* d_trace) {
 }
 
 int oake_debug_set_attention_variant(int variant) {
-  if (variant < 0 || variant > 127 || !attention_variant_supported(variant)) return OAKE_ERR_UNSUPPORTED;
+  if (variant < 0 || variant > 255 || !attention_variant_supported(variant)) return OAKE_ERR_UNSUPPORTED;
   t_debug_opts.attention_variant = variant;
   return OAKE_OK;
 }
@@ -1776,7 +1800,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
       h->opts.gemm_panel = value;
       return OAKE_OK;
     case OAKE_OPT_ATTENTION_VARIANT:
-      if (value < 0 || value > 127 || !attention_variant_supported(value))
+      if (value < 0 || value > 255 || !attention_variant_supported(value))
         return fail(h, OAKE_ERR_INVALID, "attention variant " + std::to_string(value) + " is not in this build (production: 31)");
       h->opts.attention_variant = value;
       return OAKE_OK;

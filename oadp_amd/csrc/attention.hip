@@ -903,6 +903,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #if OAKE_LAB
 #include "attention_lab_full.inc"
 #endif
+#include "attention_head.inc"
 
 
 __global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out) {
@@ -926,17 +927,16 @@ __global__ void tr_read_probe_kernel(const uint16_t* __restrict__ in, uint16_t* 
 //  32  L > 128: one block of eight waves per (crop, head) in attention_coop_kernel (else two of four) — slower, off
 //  64  64 < L <= 208: the whole K / V of a head in LDS by LDS-DMA, no barrier in the key loop (attention_full_kernel)
 //      — the same speed as the cooperative kernel, off
+// 128  192 < L <= 208 without a causal mask (objects mode, L = 197): one block per (crop, head), the whole S^T of a
+//      32-query unit in registers, one-pass softmax (attention_head_kernel, attention_head.inc)
 namespace {
 struct AttnBits {
-  bool use_tr, q32, coop, fuse_obj, pair, coop8, full;
+  bool use_tr, q32, coop, fuse_obj, pair, coop8, full, head;
   explicit AttnBits(const LaunchOpts* o) {
-#if OAKE_LAB
-    const int v = o ? o->attention_variant : 31;
-#else
-    const int v = 31;  // (production: the one configuration; oake_set_option rejects the others)
-    (void)o;
-#endif
+    // (production: 159, or 31 = the cooperative kernel at L = 197 for A/B runs; oake_set_option rejects the others)
+    const int v = o ? o->attention_variant : kAttentionVariantDefault;
     use_tr = v & 1; q32 = v & 2; coop = v & 4; fuse_obj = v & 8; pair = v & 16; coop8 = v & 32; full = v & 64;
+    head = v & 128;
   }
 };
 }  // namespace
@@ -971,15 +971,16 @@ static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, i
 
 bool attention_variant_supported(int v) {
 #if OAKE_LAB
-  return v >= 0 && v <= 127;
+  return v >= 0 && v <= 255;
 #else
-  return v == 31;
+  return v == 31 || v == kAttentionVariantDefault;
 #endif
 }
 
 bool attention_fuses_object_token(int L, const LaunchOpts* opts) {
   // needs the cooperative kernel and a wave without queries in the last block of each head
   const AttnBits b(opts);
+  if (b.head && b.use_tr && b.fuse_obj && head_supported(L, kHeadNKT, true)) return true;  // a query tile of its own
 #if OAKE_LAB
   const bool full = b.full && L <= kFullMaxL;                  // attention_full_kernel: four waves per block
 #else
@@ -999,6 +1000,26 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
   if (qkv_y != nullptr && mask_dtype != DT_F32 && mask_dtype != DT_F16) return hipErrorInvalidValue;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
+  if (bits.head && bits.use_tr && !causal && head_supported(L, kHeadNKT, qkv_y != nullptr)) {
+    const int n_items = n * heads;
+    const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
+    constexpr int lds = head_lds_bytes(kHeadNKT);
+    static DynLdsAttr attr16, attrbf;
+    if (dtype16 == DT_F16) {
+      auto kern = attention_head_kernel<f16_t, kHeadNKT>;
+      if (hipError_t e = attr16.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+      OAKE_LAUNCH(kern, dim3(n_items), dim3(256), lds, s, reinterpret_cast<const f16_t*>(qkv),
+                  reinterpret_cast<f16_t*>(out), L, heads, obj, n_items);
+    } else if (dtype16 == DT_BF16) {
+      auto kern = attention_head_kernel<bf16_t, kHeadNKT>;
+      if (hipError_t e = attrbf.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+      OAKE_LAUNCH(kern, dim3(n_items), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(qkv),
+                  reinterpret_cast<bf16_t*>(out), L, heads, obj, n_items);
+    } else {
+      return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
 #if OAKE_LAB
   if (bits.coop && bits.use_tr && bits.full && L > 64 && L <= kFullMaxL) {
     const int QG = (L + 127) / 128;

@@ -30,11 +30,13 @@ enum GemmEpi {
 
 // Kernel-selection switches of one caller (a handle, or the calling thread's handle-less oake_debug_* entry
 // points).  No process-wide state: two handles / lanes never see each other's settings.
+constexpr int kAttentionVariantDefault = 159;  // attention.hip: bits 1 | 2 | 4 | 8 | 16 | 128
+
 struct LaunchOpts {
   int gemm_variant = -1;   // -1 = automatic per shape, else a forced tile configuration (csrc/gemm.hip)
   int gemm_panel = 0;      // tile order: 0 default, n > 0 N panels of n tiles, n < 0 M slabs of -n tiles
   unsigned long long* gemm_trace = nullptr;  // device buffer for per-tile cycle stamps, or nullptr
-  int attention_variant = 31;                // bits: see oake_debug_set_attention_variant
+  int attention_variant = kAttentionVariantDefault;  // bits: see oake_debug_set_attention_variant
   int cu_count = 0;        // compute units the launch stream may use (0 = all of the device): a handle driven on a
                            // CU-masked stream (hipExtStreamCreateWithCUMask) sizes its persistent grids to that
 };

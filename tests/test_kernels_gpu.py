@@ -181,15 +181,17 @@ def _attention_ref(qkv, n, l, heads):
 
 # bit 2: K / V shared through LDS for l > 64; bit 4: persistent loader-wave kernel for l <= 64; bit 5 (63):
 # eight-wave blocks for l > 128 (197, 130, 300 below); bit 6 (95): whole K / V in LDS for 64 < l <= 208
-@pytest.mark.parametrize('use_tr', [0, 1, 2, 3, 7, 31, 63, 95])
+# bit 7 (159, the default): one block per head, one-pass softmax for 192 < l <= 208 (197 and the three seam shapes)
+@pytest.mark.parametrize('use_tr', [0, 1, 2, 3, 7, 31, 63, 95, 159])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('n,l,heads', [(1, 50, 2), (3, 50, 12), (2, 197, 2), (5, 64, 3), (2, 17, 1),
                                        (1, 130, 1), (3, 77, 8), (2, 65, 1), (1, 300, 2), (1, 1, 1),
                                        (64, 50, 12), (7, 33, 5),
                                        # a last chunk of 49..63 keys: four key tiles, the last one partly valid
-                                       (1, 114, 2), (4, 182, 10), (2, 253, 9), (1, 127, 5), (3, 113, 3)])
+                                       (1, 114, 2), (4, 182, 10), (2, 253, 9), (1, 127, 5), (3, 113, 3),
+                                       (3, 197, 12), (2, 193, 1), (1, 208, 3), (5, 200, 2), (1, 192, 2), (1, 209, 2)])
 def test_attention(lib, lab, cuda, dtype, n, l, heads, use_tr):
-    lib = lib if use_tr == 31 else lab
+    lib = lib if use_tr in (31, 159) else lab
     g = torch.Generator(device='cpu').manual_seed(n * 100 + l + heads)
     qkv = torch.randn(n * l, 3 * heads * 64, generator=g)
     qkv[:, :heads * 64] *= 0.35  # pre-scaled q: scores ~ N(0, 2.8^2): a peaky softmax
@@ -201,10 +203,55 @@ def test_attention(lib, lab, cuda, dtype, n, l, heads, use_tr):
         assert rc == 0
         torch.cuda.synchronize()
     finally:
-        lib.oake_debug_set_attention_variant(31)
+        lib.oake_debug_set_attention_variant(159)
     ref = _attention_ref(qkv, n, l, heads)
     tol = 3e-3 if dtype == torch.float16 else 2e-2
     torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
+
+
+MASK_DT = {torch.float32: _lib.OAKE_F32, torch.float16: _lib.OAKE_F16}
+
+
+@pytest.mark.parametrize('variant', [31, 159])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('mask_dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('n,l,heads', [(2, 197, 2), (5, 197, 12), (1, 194, 1), (3, 201, 3)])
+def test_attention_with_object_token(lib, cuda, dtype, mask_dtype, n, l, heads, variant):
+    """The objects-mode object token fused into the patch stream's attention (oadp/oake/objects.py:232-247): one
+    extra query per sequence over the rows 1..l-1 (bias -100 * mask) and its own key / value.  Both forms the product
+    carries: the cooperative kernel's idle wave (31) and attention_head_kernel's own query tile (159)."""
+    c = heads * 64
+    g = torch.Generator(device='cpu').manual_seed(n * 1000 + l + heads)
+    qkv = torch.randn(n * l, 3 * c, generator=g)
+    qkv[:, :c] *= 0.35
+    qkv_y = torch.randn(n, 3 * c, generator=g)
+    qkv_y[:, :c] *= 0.35
+    mask = (torch.rand(n, l - 1, generator=g) < 0.4).float()
+    mask[0] = 0  # an all-foreground crop
+    qkv, qkv_y = qkv.to(dtype).to(cuda), qkv_y.to(dtype).to(cuda)
+    mask_d = mask.to(mask_dtype).to(cuda)
+    out = torch.zeros(n * l, c, dtype=dtype, device=cuda)
+    out_y = torch.zeros(n, c, dtype=dtype, device=cuda)
+    lib.oake_debug_set_attention_variant(variant)
+    try:
+        rc = lib.oake_debug_attention_objects(qkv.data_ptr(), qkv_y.data_ptr(), mask_d.data_ptr(), MASK_DT[mask_dtype],
+                                              out.data_ptr(), out_y.data_ptr(), n, l, heads, DT[dtype], _stream())
+        if variant == 31 and l > 128 + 96:
+            assert rc == _lib.OAKE_ERR_UNSUPPORTED
+            return
+        assert rc == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.oake_debug_set_attention_variant(159)
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    torch.testing.assert_close(out.float(), _attention_ref(qkv, n, l, heads), rtol=tol, atol=tol)
+    q, k, v = qkv.float().view(n, l, 3, heads, 64).permute(2, 0, 3, 1, 4)          # [n, h, l, 64]
+    qy, ky, vy = qkv_y.float().view(n, 1, 3, heads, 64).permute(2, 0, 3, 1, 4)     # [n, h, 1, 64]
+    keys, vals = torch.cat([k[:, :, 1:], ky], 2), torch.cat([v[:, :, 1:], vy], 2)
+    bias = torch.cat([-100.0 * mask.to(cuda), torch.zeros(n, 1, device=cuda)], 1)[:, None, None, :]
+    p = torch.softmax(qy @ keys.transpose(-1, -2) + bias, dim=-1)
+    ref_y = (p @ vals).permute(0, 2, 1, 3).reshape(n, c)
+    torch.testing.assert_close(out_y.float(), ref_y, rtol=tol, atol=tol)
 
 
 def test_tr_read_semantics(lib, cuda):
@@ -286,7 +333,9 @@ def test_production_library_refuses_lab_variants(lib, lab):
     assert lib.oake_debug_set_gemm_variant(12) == lab.oake_debug_set_gemm_variant(12) == _lib.OAKE_ERR_UNSUPPORTED
     lib.oake_debug_set_gemm_variant(-1)
     lab.oake_debug_set_gemm_variant(-1)
-    for v in (0, 7, 30, 63, 95, 128, -1):
+    for v in (0, 7, 30, 63, 95, 128, 191, 255, 256, -1):
         assert lib.oake_debug_set_attention_variant(v) == _lib.OAKE_ERR_UNSUPPORTED
-    assert lib.oake_debug_set_attention_variant(31) == _lib.OAKE_OK
-    assert lab.oake_debug_set_attention_variant(95) == _lib.OAKE_OK and lab.oake_debug_set_attention_variant(31) == _lib.OAKE_OK
+    assert lib.oake_debug_set_attention_variant(31) == _lib.OAKE_OK  # (the cooperative kernel at 197 keys: A/B runs)
+    assert lib.oake_debug_set_attention_variant(159) == _lib.OAKE_OK
+    assert lab.oake_debug_set_attention_variant(95) == _lib.OAKE_OK and lab.oake_debug_set_attention_variant(255) == _lib.OAKE_OK
+    assert lab.oake_debug_set_attention_variant(159) == _lib.OAKE_OK
