@@ -1086,7 +1086,7 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
         const char* qkv_y = reinterpret_cast<const char*>(h->qkv) + (size_t)T * 3 * C * 2;
         char* att_y = reinterpret_cast<char*>(h->att) + (size_t)T * C * 2;
         RUNK(h, s, "cls_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
-             launch_object_attention(h->dt16, h->qkv, qkv_y, h->zero_mask, DT_F16, att_y, nb, L, c.heads, s));
+             launch_object_attention(h->dt16, h->qkv, qkv_y, h->zero_mask, DT_F16, att_y, nb, L, c.heads, s, &h->opts));
         rc = mlp_rows(h, s, w, T, nb, "_cls");
       }
       h->stat_fused = fused;
@@ -1214,7 +1214,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
       const bool fuse = !last && attention_fuses_object_token(L, &h->opts);
       if (!fuse)
         RUNK(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
-            launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s));
+            launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s, &h->opts));
       if (!last) {
         const int Lp = ((L + 63) / 64) * 64;
         RUNK(h, s, "attention", 4.0 * nb * c.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,

@@ -969,6 +969,23 @@ static hipError_t attn_pair_launch_t(const void* qkv, void* out, int n, int L, i
   return hipGetLastError();
 }
 
+// attention_head_kernel; obj_only: the object token alone (the last layer of objects mode)
+static hipError_t launch_attention_head(int dtype16, const void* qkv, void* out, int n, int L, int heads, hipStream_t s,
+                                        const void* qkv_y, const void* mask, int mask_dtype, void* out_y,
+                                        int obj_only) {
+  const int n_items = n * heads;
+  const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
+  if (dtype16 == DT_F16)
+    OAKE_LAUNCH((attention_head_kernel<f16_t, kHeadNKT>), dim3(n_items), dim3(256), 0, s,
+                reinterpret_cast<const f16_t*>(qkv), reinterpret_cast<f16_t*>(out), L, heads, obj, n_items, obj_only);
+  else if (dtype16 == DT_BF16)
+    OAKE_LAUNCH((attention_head_kernel<bf16_t, kHeadNKT>), dim3(n_items), dim3(256), 0, s,
+                reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(out), L, heads, obj, n_items, obj_only);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 bool attention_variant_supported(int v) {
 #if OAKE_LAB
   return v >= 0 && v <= 255;
@@ -1000,26 +1017,8 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
   if (qkv_y != nullptr && mask_dtype != DT_F32 && mask_dtype != DT_F16) return hipErrorInvalidValue;
   if (L <= 0 || heads <= 0) return hipErrorInvalidValue;
   if ((long)n * heads * ((L + 31) / 32) > 0x7fffffffL) return hipErrorInvalidValue;
-  if (bits.head && bits.use_tr && !causal && head_supported(L, kHeadNKT, qkv_y != nullptr)) {
-    const int n_items = n * heads;
-    const ObjArgs obj{qkv_y, mask, out_y, mask_dtype == DT_F16 ? 1 : 0};
-    constexpr int lds = head_lds_bytes(kHeadNKT);
-    static DynLdsAttr attr16, attrbf;
-    if (dtype16 == DT_F16) {
-      auto kern = attention_head_kernel<f16_t, kHeadNKT>;
-      if (hipError_t e = attr16.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-      OAKE_LAUNCH(kern, dim3(n_items), dim3(256), lds, s, reinterpret_cast<const f16_t*>(qkv),
-                  reinterpret_cast<f16_t*>(out), L, heads, obj, n_items);
-    } else if (dtype16 == DT_BF16) {
-      auto kern = attention_head_kernel<bf16_t, kHeadNKT>;
-      if (hipError_t e = attrbf.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-      OAKE_LAUNCH(kern, dim3(n_items), dim3(256), lds, s, reinterpret_cast<const bf16_t*>(qkv),
-                  reinterpret_cast<bf16_t*>(out), L, heads, obj, n_items);
-    } else {
-      return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-  }
+  if (bits.head && bits.use_tr && !causal && head_supported(L, kHeadNKT, qkv_y != nullptr))
+    return launch_attention_head(dtype16, qkv, out, n, L, heads, s, qkv_y, mask, mask_dtype, out_y, 0);
 #if OAKE_LAB
   if (bits.coop && bits.use_tr && bits.full && L > 64 && L <= kFullMaxL) {
     const int QG = (L + 127) / 128;
@@ -1123,9 +1122,14 @@ static hipError_t obj_attn_t(const void* qkv_x, const void* qkv_y, const void* m
 
 hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* qkv_y,
                                    const void* mask, int mask_dtype, void* out, int n, int L,
-                                   int heads, hipStream_t s) {
+                                   int heads, hipStream_t s, const LaunchOpts* opts) {
   if (n <= 0) return hipSuccess;
   if (L < 2 || L > kObjMaxKeys) return hipErrorInvalidValue;
+  if (mask_dtype != DT_F32 && mask_dtype != DT_F16) return hipErrorInvalidValue;
+  // K / V of the head by LDS-DMA and the token as one MFMA query tile where attention_head_kernel covers L (objects
+  // mode's last layer: 40 -> 12 us per 128 crops against the one-wave VALU kernel below)
+  if (const AttnBits bits(opts); bits.head && bits.use_tr && head_supported(L, kHeadNKT, true))
+    return launch_attention_head(dtype16, qkv_x, nullptr, n, L, heads, s, qkv_y, mask, mask_dtype, out, 1);
   if (dtype16 == DT_F16) return obj_attn_t<f16_t>(qkv_x, qkv_y, mask, mask_dtype, out, n, L, heads, s);
   if (dtype16 == DT_BF16) return obj_attn_t<bf16_t>(qkv_x, qkv_y, mask, mask_dtype, out, n, L, heads, s);
   return hipErrorInvalidValue;

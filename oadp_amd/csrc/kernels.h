@@ -143,7 +143,7 @@ hipError_t launch_attention(int dtype16, const void* qkv, void* out, int n, int 
                             const void* mask = nullptr, int mask_dtype = 0, void* out_y = nullptr,
                             const LaunchOpts* opts = nullptr);
 bool attention_fuses_object_token(int L, const LaunchOpts* opts = nullptr);
-// attention kernel forms this build carries (production: 31 only; lab build: every bit set)
+// attention kernel forms this build carries (production: 159 and 31; lab build: every bit set)
 bool attention_variant_supported(int v);
 
 // Object-token attention (oadp/oake/objects.py:232-247): one query per crop (qkv_y row n),
@@ -151,7 +151,7 @@ bool attention_variant_supported(int v);
 // additive bias = -100 * mask[n, p] on patch keys, 0 on the object token.
 hipError_t launch_object_attention(int dtype16, const void* qkv_x, const void* qkv_y,
                                    const void* mask, int mask_dtype, void* out, int n, int L,
-                                   int heads, hipStream_t s);
+                                   int heads, hipStream_t s, const LaunchOpts* opts = nullptr);
 
 // ---- attention + out_proj + residual in one kernel (attn_out.hip) ------------------------------
 // For sequences of at most 64 tokens on a 16-bit residual stream, ViT-B geometry (12 heads, width 768):
