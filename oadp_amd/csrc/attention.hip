@@ -17,6 +17,7 @@
 //     (one chunk) and L = 197 (four chunks).
 // object_attention_kernel: the reference's object-token stream (oadp/oake/objects.py:232-247) has a
 // single query per crop; it is a VALU/LDS kernel, one wavefront per (crop, head).
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 

@@ -1,7 +1,9 @@
 """Randomised shapes through the GEMM epilogues and the attention kernels against fp32 torch (GPU box): M from 1
 to 30 000 (ragged tiles, one row, several tiles per persistent block), N a multiple of 8 up to 3 200, K a multiple of
 64 up to 3 072, f16 and bf16, the automatic kernel choice; bias / QuickGELU / LayerNorm-folded / residual epilogues
-incl. the per-slice row sums; attention with 1..6 items, 1..300 keys, 1..12 heads.  usage: kernel_fuzz.py [n=200] [seed=0]"""
+incl. the per-slice row sums; attention with 1..6 items, 1..300 keys, 1..12 heads; attention with the objects-mode
+object token fused in (65..224 keys, half of the cases in attention_head_kernel's 193..208; random masks, one crop all
+foreground), both kernel forms the product carries.  usage: kernel_fuzz.py [n=200] [seed=0]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -36,7 +38,7 @@ for it in range(n_cases):
     bias = torch.randn(n, generator=g).to(dev)
     info = (m, n, k, str(dtype).split('.')[-1])
     tol = 3e-3 if dtype == torch.float16 else 2.5e-2
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     if kind == 0:    # bias / QuickGELU epilogues
         gelu = int(rng.integers(0, 2))
         c = torch.full((m, n), float('nan'), dtype=dtype, device=dev)
@@ -74,6 +76,34 @@ for it in range(n_cases):
         if rc: bad += 1; print('RC', rc, 'resid16', info); continue
         ref = x0.float() + a.float() @ w.float().t() + bias
         check('resid16', x, ref, 1.5 * tol, info)
+    elif kind == 4:  # attention + the object token (oadp/oake/objects.py:232-247)
+        nn_, heads = int(rng.integers(1, 40)), int(rng.integers(1, 13))
+        L = int(rng.integers(193, 209)) if rng.random() < 0.5 else int(rng.integers(65, 225))
+        variant = 159 if rng.random() < 0.7 else 31
+        mdt = torch.float16 if rng.random() < 0.5 else torch.float32
+        c_ = heads * 64
+        qkv = torch.randn(nn_ * L, 3 * c_, generator=g); qkv[:, :c_] *= 0.35
+        qy_ = torch.randn(nn_, 3 * c_, generator=g); qy_[:, :c_] *= 0.35
+        mask = (torch.rand(nn_, L - 1, generator=g) < rng.random()).float(); mask[0] = 0
+        qkv, qy_ = qkv.to(dtype).to(dev), qy_.to(dtype).to(dev)
+        md = mask.to(mdt).to(dev)
+        out = torch.zeros(nn_ * L, c_, dtype=dtype, device=dev)
+        oy = torch.zeros(nn_, c_, dtype=dtype, device=dev)
+        lib.oake_debug_set_attention_variant(variant)
+        rc = lib.oake_debug_attention_objects(qkv.data_ptr(), qy_.data_ptr(), md.data_ptr(),
+                                              _lib.OAKE_F16 if mdt == torch.float16 else _lib.OAKE_F32, out.data_ptr(),
+                                              oy.data_ptr(), nn_, L, heads, DT[dtype], s)
+        lib.oake_debug_set_attention_variant(159)
+        if rc == _lib.OAKE_ERR_UNSUPPORTED: continue  # (no place for the token at this L in this form)
+        if rc: bad += 1; print('RC', rc, 'attention_objects', (nn_, L, heads, variant)); continue
+        q, kk, v = qkv.float().view(nn_, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        ref = (torch.softmax(q @ kk.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(nn_ * L, c_)
+        check('attention_objects.x', out, ref, tol, (nn_, L, heads, variant, info[3]))
+        qq, ky, vy = qy_.float().view(nn_, 1, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        keys, vals = torch.cat([kk[:, :, 1:], ky], 2), torch.cat([v[:, :, 1:], vy], 2)
+        bias_ = torch.cat([-100.0 * mask.to(dev), torch.zeros(nn_, 1, device=dev)], 1)[:, None, None, :]
+        refy = (torch.softmax(qq @ keys.transpose(-1, -2) + bias_, dim=-1) @ vals).permute(0, 2, 1, 3).reshape(nn_, c_)
+        check('attention_objects.y', oy, refy, tol, (nn_, L, heads, variant, info[3]))
     else:            # attention
         nn_, L, heads = int(rng.integers(1, 7)), int(rng.integers(1, 301)), int(rng.integers(1, 13))
         qkv = torch.randn(nn_ * L, 3 * heads * 64, generator=g)
