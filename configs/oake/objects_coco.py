@@ -13,4 +13,8 @@ def _split(name):
 train, val = _split('train'), _split('val')
 log = dict(interval=5)
 mini_batch_size = 512   # crops per model.visual(objects, masks) call, as the reference
-batch_size = 512        # crops gathered across images before an encoder pass (build-side batching)
+# crops gathered across images before they go down to the GPU (build-side batching).  One flush = one crop job list,
+# one upload of masks, one native encode call that the library cuts into equal passes of <= 128 crops, one download:
+# 8 images' worth keeps the fixed costs of a flush under 1 % (files -> .pth on one MI355X, 2000 images: 83.0 images/s
+# at 1024, 90.4 at 2400 = the encoder-only rate of bench.py --mode objects; profiles/r04/sweep_objects_lookahead_batch.log)
+batch_size = 2400

@@ -123,8 +123,10 @@ _OBJECTS_HOOKS = dict(visual_pre='visual_forward_pre', transformer_pre='transfor
 class VisionTransformer(_HookPoint):
 
     def __init__(self, state_dict: Mapping[str, torch.Tensor], *, compute_dtype=torch.float16,
-                 residual_dtype: torch.dtype | None = None, max_batch: int = 256,
+                 residual_dtype: torch.dtype | None = None, max_batch: int = 512,
                  device: int | None = None, lib=None) -> None:
+        # (max_batch: an upper bound on the crops per encoder pass — the library caps a pass at ~25.6 k token rows,
+        # i.e. 512 crops at 50 tokens, 128 at 197 — csrc/api.hip oake_create)
         super().__init__()
         sd = {k: v.detach().to('cpu', torch.float32).contiguous()
               for k, v in state_dict.items() if k.startswith(VISION_PREFIX)}

@@ -1053,8 +1053,12 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
   const size_t img_bytes = (size_t)3 * c.image_size * c.image_size * dtype_size(in_dtype);
   const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
 
-  for (int b0 = 0; b0 < n; b0 += c.max_batch) {
-    const int nb = std::min(c.max_batch, n - b0);
+  // passes of equal size (600 crops under a cap of 128: 5 x 120, not 4 x 128 + 88 — a short last pass runs the
+  // GEMMs on a fraction of the chip); a crop's result depends on its pass only through the tile shapes the small
+  // last-layer GEMMs pick for the pass's row count (rounding: <= 3e-4 on the unit-norm output, tests/test_encoder_gpu.py)
+  const int per_pass = n > 0 ? (n + (n + c.max_batch - 1) / c.max_batch - 1) / ((n + c.max_batch - 1) / c.max_batch) : 1;
+  for (int b0 = 0; b0 < n; b0 += per_pass) {
+    const int nb = std::min(per_pass, n - b0);
     const int T = nb * L;
     const char* imgs = reinterpret_cast<const char*>(d_images) + (size_t)b0 * img_bytes;
     char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
@@ -1173,8 +1177,12 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
   const size_t mask_bytes = (size_t)h->p2 * dtype_size(mask_dtype);
   const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
 
-  for (int b0 = 0; b0 < n; b0 += c.max_batch) {
-    const int nb = std::min(c.max_batch, n - b0);
+  // passes of equal size (600 crops under a cap of 128: 5 x 120, not 4 x 128 + 88 — a short last pass runs the
+  // GEMMs on a fraction of the chip); a crop's result depends on its pass only through the tile shapes the small
+  // last-layer GEMMs pick for the pass's row count (rounding: <= 3e-4 on the unit-norm output, tests/test_encoder_gpu.py)
+  const int per_pass = n > 0 ? (n + (n + c.max_batch - 1) / c.max_batch - 1) / ((n + c.max_batch - 1) / c.max_batch) : 1;
+  for (int b0 = 0; b0 < n; b0 += per_pass) {
+    const int nb = std::min(per_pass, n - b0);
     const int T = nb * L;
     const char* imgs = reinterpret_cast<const char*>(d_objects) + (size_t)b0 * img_bytes;
     const char* masks = reinterpret_cast<const char*>(d_masks) + (size_t)b0 * mask_bytes;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import collections
 import os
 import pathlib
 import queue
@@ -363,7 +364,8 @@ class BaseValidator(ABC, Generic[T]):
     def __init__(self, name: str, model, *, dataloader: Config, log: Config | None = None,
                  batch_size: int = 256, device: torch.device | str | None = None,
                  writer_threads: int = 4, decode_threads: int = 16, prefetch: int = 512,
-                 streams: int = 2, host_threads: int = 8, writer: str = 'pth', **kwargs) -> None:
+                 streams: int = 2, host_threads: int = 8, writer: str = 'pth', lookahead: int = 1,
+                 **kwargs) -> None:
         if kwargs:  # a misspelled option must not vanish silently
             raise TypeError(f'{type(self).__name__}: unknown option(s) {sorted(kwargs)}')
         self.name = name
@@ -390,7 +392,10 @@ class BaseValidator(ABC, Generic[T]):
         # reason).  0 leaves torch's setting alone.
         self._host_threads = host_threads
         self._writer: AsyncWriter | None = None
-        self._inflight: tuple[list, Any] | None = None   # the flush whose results are still on the GPU
+        # flushes whose results are still on the GPU, oldest first: `lookahead` of them stay in flight while the host
+        # prepares the next (OAKE_LOOKAHEAD overrides)
+        self._inflight: collections.deque[tuple[list, Any]] = collections.deque()
+        self._lookahead = max(1, int(os.environ.get('OAKE_LOOKAHEAD', lookahead)))
         self._host_pool = _PinnedPool()
         # consecutive flushes alternate over `streams` lanes = (native handle, HIP stream) pairs: the
         # kernels of two independent batches fill each other's start-up and tail (GPU only)
@@ -512,15 +517,15 @@ class BaseValidator(ABC, Generic[T]):
             self.counters.images += 1
 
     def _finish_inflight(self) -> None:
-        if self._inflight is not None:
-            (batches, finish), self._inflight = self._inflight, None
+        while self._inflight:
+            batches, finish = self._inflight.popleft()
             self._submit(batches, finish())
 
     def _flush(self, pending: list[T]) -> None:
         """Encode a flush and hand its results to the writer.  ``_encode`` returns the results, or — on
         the GPU — a closure that produces them once the device has finished: then the flush stays in
         flight while the host decodes and cuts the crops of the next one, and is written out when that
-        one has been launched (one flush of look-ahead; file order is unchanged)."""
+        one has been launched (`lookahead` flushes stay in flight; file order is unchanged)."""
         if not pending:
             return
         if self._n_lanes > 1:
@@ -538,9 +543,10 @@ class BaseValidator(ABC, Generic[T]):
         else:
             results = self._encode(pending)
         if callable(results):
-            previous, self._inflight = self._inflight, (list(pending), results)
-            if previous is not None:
-                self._submit(previous[0], previous[1]())
+            self._inflight.append((list(pending), results))
+            while len(self._inflight) > self._lookahead:
+                batches, finish = self._inflight.popleft()
+                self._submit(batches, finish())
         else:
             self._finish_inflight()
             self._submit(pending, results)

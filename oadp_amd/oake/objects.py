@@ -212,8 +212,13 @@ class Validator(BaseValidator[Batch]):
         if not objects.is_cuda:
             objects = self._to_device(objects)
         embs = []
-        for i in range(math.ceil(objects.shape[0] / self._mini_batch_size)):
-            sl = slice(i * self._mini_batch_size, (i + 1) * self._mini_batch_size)
+        # On the GPU the flush goes down in ONE call: the library cuts it into equal encoder passes of at most
+        # min(mini_batch_size, ~25.6 k token rows) crops (csrc/api.hip), which is what mini_batch_size is for in the
+        # reference — a memory bound; a crop's embedding depends on its pass only through the rounding of the last
+        # layer's object-token GEMMs (tests/test_encoder_gpu.py::test_pass_cap_and_equal_passes_are_invisible).
+        step = objects.shape[0] if objects.is_cuda and objects.shape[0] else self._mini_batch_size
+        for i in range(math.ceil(objects.shape[0] / step)):
+            sl = slice(i * step, (i + 1) * step)
             embs.append(self._model.visual(objects[sl], masks[sl], normalize=True, out_dtype=torch.float16))
         on_gpu = bool(embs) and embs[0].is_cuda
         # one device -> host copy per flush, left in flight while the next flush is prepared (base._flush)

@@ -1,6 +1,8 @@
 """End-to-end parity of the HIP encoder (through oadp_amd.clip -> C ABI) against the fp32 CPU
 oracle on the same seeded weights and inputs.  Tolerance = BASELINE.json north_star: fp16
 rtol 1e-3 / atol 1e-3 on L2-normalised features and cosine >= 0.999."""
+import os
+
 import pytest
 import torch
 
@@ -293,13 +295,42 @@ def test_conv1_fp32_input_gathered_without_im2col(cuda, dtype):
     assert 'im2col' not in names and 'gemm_conv1' in names
 
 
-def test_batches_beyond_1024_crops_per_pass(cuda):
+def test_pass_cap_and_equal_passes_are_invisible(cuda):
+    """oake_create caps an encoder pass at ~25.6 k token rows (128 crops at 197 tokens) and a call is cut into equal
+    passes (300 crops: 3 x 100, not 128 + 128 + 44): a crop's embedding must not depend on either beyond the rounding
+    of the last layer's object-token GEMMs (whose tile shape follows the rows of the pass) — objects mode, ViT-B/32
+    widths, against the same crops sent down in calls of 37 (one pass each), against a handle whose cap is switched
+    off (one pass of 300), and against the oracle."""
+    arch = dict(width=768, layers=2, heads=12, mlp_dim=3072, embed_dim=512)
+    sd = synthetic_state_dict(**arch)
+    model, sd2, cfg = _objects_model(sd, arch, max_batch=512)
+    x = synthetic_images(60, seed=4).half().repeat(5, 1, 1, 1).to(cuda)  # 300 crops
+    g = torch.Generator().manual_seed(3)
+    masks = (torch.rand(300, 1, 14, 14, generator=g) < 0.3).half().to(cuda)
+    a = model.visual(x, masks, normalize=True, out_dtype=torch.float32)
+    b = torch.cat([model.visual(x[i:i + 37], masks[i:i + 37], normalize=True, out_dtype=torch.float32)
+                   for i in range(0, 300, 37)])
+    os.environ['OAKE_PASS_ROWS'] = '0'
+    try:
+        uncapped, _, _ = _objects_model(sd, arch, max_batch=512)
+        c = uncapped.visual(x, masks, normalize=True, out_dtype=torch.float32)  # one pass of 300
+    finally:
+        del os.environ['OAKE_PASS_ROWS']
+    print(f'passes of 100 vs 37: max|d|={(a - b).abs().max().item():.2e}; vs one pass of 300: {(a - c).abs().max().item():.2e}')
+    torch.testing.assert_close(a, b, rtol=0, atol=3e-4)
+    torch.testing.assert_close(a, c, rtol=0, atol=3e-4)
+    ref = l2_normalize(encode_objects_ref(sd2, cfg, x[:4].float().cpu(), masks[:4].float().cpu()))
+    _check(a[:4], ref, 1e-3, 1e-3)
+
+
+def test_batches_beyond_1024_crops_per_pass(cuda, monkeypatch):
     """max_batch > 1024: the CLS rows of the last block (M = crops per pass) are then large enough for the
     persistent GEMM, which takes its LayerNorm statistics as per-row sums — decided per GEMM from the shape
     it is actually called with, not once per pass.  Same features as 256-crop passes."""
     arch = dict(width=768, layers=2, heads=12, mlp_dim=3072, embed_dim=512)  # ViT-B/32 widths, 2 layers
     sd = synthetic_state_dict(**arch)
     x = synthetic_images(100, seed=9).half().repeat(11, 1, 1, 1).to(cuda)  # 1100 crops, 100 distinct
+    monkeypatch.setenv('OAKE_PASS_ROWS', '0')  # (no cap on the rows of a pass: this test is about M > 1024 CLS rows)
     big, _ = clip.load(sd, max_batch=1100)
     small, _ = clip.load(sd, max_batch=256)
     a = big.encode_image(x, normalize=True, out_dtype=torch.float32)
