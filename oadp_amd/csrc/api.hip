@@ -849,7 +849,7 @@ int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_
 int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   // attention + out_proj + MLP of the main token stream (qkv already computed)
   const int C = h->cfg.width, L = h->cur_len, T = nb * L;
-  const int Lp = ((L + 63) / 64) * 64;
+  const int Lp = L;  // (the profile quotes ALGORITHMIC attention FLOPs, 4 L^2 d per head: padded key / query tiles are not work)
   // L <= 64 on the 16-bit residual stream (encode_image, blocks mode): attention + out_proj + residual + the row
   // statistics of the next LayerNorm in one kernel, one workgroup per image; `att` is never written (attn_out.hip)
   if (h->fuse_attn_out && h->stat_fused && !h->text && w.out_wp && attn_out_supported(L, h->cfg.heads, C)) {
@@ -1224,7 +1224,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
         RUNK(h, s, "object_attention", 4.0 * nb * c.heads * (double)L * 64, 0.0,
             launch_object_attention(h->dt16, h->qkv, qkv_y, masks, mask_dtype, att_y, nb, L, c.heads, s, &h->opts));
       if (!last) {
-        const int Lp = ((L + 63) / 64) * 64;
+        const int Lp = L;  // (algorithmic FLOPs, as main_block_tail)
         RUNK(h, s, "attention", 4.0 * nb * c.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
             launch_attention(h->dt16, h->qkv, h->att, nb, L, c.heads, 0, s, fuse ? qkv_y : nullptr,
                              fuse ? masks : nullptr, mask_dtype, fuse ? att_y : nullptr, &h->opts));
