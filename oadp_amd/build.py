@@ -19,7 +19,7 @@ CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
 SOURCES = ['gemm.hip', 'attention.hip', 'attn_out.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
-HEADERS = ['common.h', 'kernels.h', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
+HEADERS = ['common.h', 'kernels.h', 'attention_head.inc', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'
 # instantiations that may spill: the s_memtime-stamped measurement build of attn_out (oake_debug_attn_out_trace), and
 # attn_out itself up to SPILL_SMALL bytes — its out_proj waves sit at the 168-register limit and hipcc parks a few
