@@ -112,6 +112,14 @@ struct TileMap {
 #ifndef OAKE_GEMM_W_AUX
 #define OAKE_GEMM_W_AUX 0
 #endif
+// ... and of the A operand in the residual epilogue's GEMMs alone (out_proj, c_proj: N = 768 = ONE panel of three
+// tiles, so an A row slab is read by three tiles that run side by side on one XCD and never again, while W — 1.2 / 4.7 MB
+// — is what every tile of the XCD re-reads).  Measured with 2 = nt: -1.0 % objects, -1.8 % globals
+// (profiles/r04/ab_session_resid_gemm_a_operand_nt.log): the three tiles are not in step closely enough for an
+// evict-first line to survive until its last reader.  Off.
+#ifndef OAKE_GEMM_A_AUX_RESID
+#define OAKE_GEMM_A_AUX_RESID OAKE_GEMM_A_AUX
+#endif
 #ifndef OAKE_STORE_POLICY_PARTIAL
 #define OAKE_STORE_POLICY_PARTIAL 0
 #endif
@@ -959,7 +967,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
           if (!A32 || _j >= kAPieces) {                                                      \
             if (_j < kAPieces)                                                               \
               __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koffa),                \
-                                               (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, OAKE_GEMM_A_AUX); \
+                                               (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0,           \
+                                               EPI == EPI_RESID16 ? OAKE_GEMM_A_AUX_RESID : OAKE_GEMM_A_AUX); \
             else                                                                             \
               __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                 \
                                                (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, OAKE_GEMM_W_AUX); \
