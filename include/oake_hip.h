@@ -94,7 +94,9 @@ typedef struct oake_config {
   int32_t embed_dim;
   int32_t compute_dtype;
   int32_t max_batch;      /* workspace is sized for this many crops per internal pass (the vision tower caps it at
-                             ~25 600 token rows per pass: OAKE_PASS_ROWS, csrc/api.hip) */
+                             ~25 600 token rows per pass: the environment variable OAKE_PASS_ROWS
+                             overrides the target (0 = no cap), OAKE_PASS_CROPS names the cap in crops
+                             directly; a call with more crops is cut into EQUAL passes; csrc/api.hip) */
   int32_t residual_dtype; /* element type of the residual stream x: == compute_dtype (default; the
                              reference's GPU model keeps x in fp16 too) or OAKE_F32 */
 } oake_config;

@@ -950,7 +950,7 @@ int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, 
   if (jobs.empty()) return OAKE_OK;
   long coef = 0, bnd = 0, temp = 0;
   int max_out = 1;
-  long max_ch_rw = 1, max_rh_rw = 1;
+  long max_ch_rw = 1, max_chq_rw = 1, max_rh_rw = 1;
   for (auto& j : jobs) {
     if (!j.tr && (long)j.ch > 100L * j.cw && j.rh < j.ch) {  // Pillow resamples these vertically first
       std::swap(j.cw, j.ch); std::swap(j.rw, j.rh); std::swap(j.sx0, j.sy0); std::swap(j.cx, j.cy);
@@ -965,6 +965,7 @@ int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, 
     j.temp_off = temp; temp += (long)j.ch * j.rw * 3;
     max_out = std::max(max_out, std::max(j.rw, j.rh));
     max_ch_rw = std::max(max_ch_rw, (long)j.ch * j.rw);
+    max_chq_rw = std::max(max_chq_rw, (long)((j.ch + 3) / 4) * j.rw);  // (resample_h_kernel: four rows per thread)
     max_rh_rw = std::max(max_rh_rw, (long)j.rh * j.rw);
   }
   if (max_ch_rw > 0x7fffffffL || max_rh_rw > 0x7fffffffL) return fail(h, OAKE_ERR_INVALID, "crop too large");
@@ -982,7 +983,7 @@ int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, 
   else
     bytes += (double)jobs.size() * out_size * out_size * 3 * (out_dtype == DT_F32 ? 4 : 2);
   RUN(h, s, "resample", 0.0, bytes,
-      launch_resample(h->rs_jobs, (int)jobs.size(), max_out, max_ch_rw, max_rh_rw, h->rs_coef, h->rs_bounds,
+      launch_resample(h->rs_jobs, (int)jobs.size(), max_out, max_chq_rw, max_rh_rw, h->rs_coef, h->rs_bounds,
                       h->rs_temp, out_size, mean3, std3, d_out, out_dtype, s));
   return OAKE_OK;
 }

@@ -204,8 +204,9 @@ struct ResampleJob {
 };
 // out_dtype DT_F32 / DT_F16: normalised crops, job j -> out[j.out_row];
 // DT_U8: every job writes its own uint8 HWC image (rh x rw) to job.u8_out (`out` unused).
-// max_ch_rw / max_rh_rw: the largest ch*rw / rh*rw over the jobs (grid sizing).
-hipError_t launch_resample(const ResampleJob* d_jobs, int njobs, int max_out, long max_ch_rw, long max_rh_rw,
+// max_chq_rw / max_rh_rw: the largest ceil(ch / 4) * rw (the horizontal pass: four rows per thread) / rh * rw over
+// the jobs (grid sizing).
+hipError_t launch_resample(const ResampleJob* d_jobs, int njobs, int max_out, long max_chq_rw, long max_rh_rw,
                            int32_t* d_coef, int32_t* d_bounds, uint8_t* d_temp, int out_size,
                            const float* mean3, const float* std3, void* out, int out_dtype, hipStream_t s);
 
