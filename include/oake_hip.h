@@ -321,7 +321,14 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               attention output never reaches memory (csrc/attn_out.hip).  Parity-tested; measured
  *                               slower than the two separate launches (39 vs 36 us per layer at batch 256: the
  *                               out_proj weights stream through each CU's 64 B/clk vector-memory path once per
- *                               image), so it is opt-in.  Default 0.
+ *                               image): the kernel is in the lab build liboake_hip_lab.so only; the
+ *                               production library answers OAKE_ERR_INVALID to a non-zero value.  Default 0.
+ *   OAKE_OPT_PASS_CROPS         crops per internal encoder pass (vision handles).  get: the cap in force — what
+ *                               oake_create derived from cfg.max_batch and the ~25 600-token-row target
+ *                               (OAKE_PASS_ROWS).  set: a bound >= 1; the cap becomes min(value, the cap the handle
+ *                               was created with: the workspace is sized for that) — what the reference's
+ *                               `mini_batch_size` is: a memory bound on one pass [REF oadp/oake/objects.py:321-331].  A call's crops are cut into
+ *                               equal passes under the cap.
  */
 enum {
   OAKE_OPT_CLS_LAST = 1,
@@ -330,7 +337,8 @@ enum {
   OAKE_OPT_ATTENTION_VARIANT = 4,
   OAKE_OPT_PATCH_DIRECT = 5,
   OAKE_OPT_CU_COUNT = 6,
-  OAKE_OPT_FUSE_ATTN_OUT = 7
+  OAKE_OPT_FUSE_ATTN_OUT = 7,
+  OAKE_OPT_PASS_CROPS = 8
 };
 OAKE_API int oake_set_option(oake_handle* h, int option, int value);
 OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);

@@ -13,6 +13,7 @@ OAKE_OPT_CLS_LAST, OAKE_OPT_GEMM_VARIANT, OAKE_OPT_GEMM_PANEL, OAKE_OPT_ATTENTIO
 OAKE_OPT_PATCH_DIRECT = 5
 OAKE_OPT_CU_COUNT = 6
 OAKE_OPT_FUSE_ATTN_OUT = 7
+OAKE_OPT_PASS_CROPS = 8
 ABI_VERSION = 3
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library

@@ -18,7 +18,8 @@ ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
-SOURCES = ['gemm.hip', 'attention.hip', 'attn_out.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
+LAB_ONLY_SOURCES = ['attn_out.hip']  # kernels that lost their A/B: liboake_hip_lab.so only
 HEADERS = ['common.h', 'kernels.h', 'attention_head.inc', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'
 # instantiations that may spill: the s_memtime-stamped measurement build of attn_out (oake_debug_attn_out_trace), and
@@ -111,14 +112,16 @@ def build_library(force: bool = False, verbose: bool = False, lab: bool = True) 
     BUILD.mkdir(parents=True, exist_ok=True)
     jobs = [(src, False) for src in SOURCES]
     if lab and not os.environ.get('OAKE_LIB_OUT'):
-        jobs += [(src, True) for src in SOURCES if src in ('gemm.hip', 'attention.hip', 'attn_out.hip', 'api.hip')]
+        jobs += [(src, True) for src in SOURCES if src in ('gemm.hip', 'attention.hip', 'api.hip')]
+        jobs += [(src, True) for src in LAB_ONLY_SOURCES]
     with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(lambda j: _compile(j[0], force, j[1]), jobs))
     prod = objs[:len(SOURCES)]
     _link(prod, LIB, force)
     if len(objs) > len(SOURCES):
         labobj = {j[0]: o for j, o in zip(jobs[len(SOURCES):], objs[len(SOURCES):])}
-        _link([labobj.get(src, po) for src, po in zip(SOURCES, prod)], LAB_LIB, force)
+        _link([labobj.get(src, po) for src, po in zip(SOURCES, prod)] + [labobj[src] for src in LAB_ONLY_SOURCES],
+              LAB_LIB, force)
     if verbose:
         print(f'built {LIB}' + (f' and {LAB_LIB.name}' if len(objs) > len(SOURCES) else ''))
     return LIB

@@ -168,15 +168,15 @@ class VisionTransformer(_HookPoint):
     OPTIONS = dict(cls_last=_lib.OAKE_OPT_CLS_LAST, gemm_variant=_lib.OAKE_OPT_GEMM_VARIANT,
                    gemm_panel=_lib.OAKE_OPT_GEMM_PANEL, attention_variant=_lib.OAKE_OPT_ATTENTION_VARIANT,
                    patch_direct=_lib.OAKE_OPT_PATCH_DIRECT, cu_count=_lib.OAKE_OPT_CU_COUNT,
-                   fuse_attn_out=_lib.OAKE_OPT_FUSE_ATTN_OUT)
+                   fuse_attn_out=_lib.OAKE_OPT_FUSE_ATTN_OUT, pass_crops=_lib.OAKE_OPT_PASS_CROPS)
 
     def set_option(self, name: str, value: int) -> None:
         """Per-model kernel-selection switch (``oake_set_option`` on every lane's handle, now and for
         handles created later): cls_last, gemm_variant, gemm_panel, attention_variant."""
         key = self.OPTIONS[name]
-        self._options[key] = int(value)
-        for h, _ in self._lanes.values():
+        for h, _ in self._lanes.values():  # (a refused value raises here and is not remembered for later handles)
             _lib.check(self._lib, h, self._lib.oake_set_option(h, key, int(value)), 'oake_set_option')
+        self._options[key] = int(value)
 
     # -- reference surface -----------------------------------------------------------------
     def interpolate_positional_embedding(self, size: tuple[int, int]) -> torch.Tensor:
@@ -287,11 +287,42 @@ class VisionTransformer(_HookPoint):
                 raise ValueError(f'state_dict lacks {missing} vision-tower tensors')
             for opt, value in self._options.items():
                 _lib.check(lib, h, lib.oake_set_option(h, opt, value), 'oake_set_option')
+            self._apply_pass_limit(h)
         except Exception:
             lib.oake_destroy(h)
             raise
         self._lanes[self.lane] = (h, key)
         return h
+
+    def get_option(self, name: str) -> int | None:
+        """``oake_get_option`` on the current lane's handle (None before the first call created it)."""
+        h = self.handle
+        if h is None:
+            return None
+        v = C.c_int(0)
+        _lib.check(self._lib, h, self._lib.oake_get_option(h, self.OPTIONS[name], C.byref(v)), 'oake_get_option')
+        return v.value
+
+    # crops per encoder pass: the reference's `mini_batch_size` [REF oadp/oake/objects.py:321-331] is a memory bound on
+    # one pass; here a call's crops are cut into equal passes by the library (cap = min(max_batch, ~25.6 k token rows,
+    # OAKE_PASS_ROWS) at handle creation) and `pass_limit` lowers that cap — it never raises it
+    _pass_limit: int | None = None
+
+    @property
+    def pass_limit(self) -> int | None:
+        return self._pass_limit
+
+    @pass_limit.setter
+    def pass_limit(self, n: int | None) -> None:
+        self._pass_limit = None if n is None else max(1, int(n))
+        for h, _ in self._lanes.values():
+            self._apply_pass_limit(h)
+
+    def _apply_pass_limit(self, h) -> None:
+        if self._pass_limit is None:
+            return
+        _lib.check(self._lib, h, self._lib.oake_set_option(h, _lib.OAKE_OPT_PASS_CROPS, self._pass_limit),
+                   'oake_set_option')
 
     def close(self) -> None:
         for h, _ in self._lanes.values():

@@ -76,6 +76,7 @@ struct oake_handle {
   int device = 0;
   int grid = 0, tokens = 0, p2 = 0, kpatch = 0;
   int cur_len = 0;            // tokens per sequence of the pass in flight (text: <= tokens)
+  int pass_cap = 0;           // crops per pass the workspace was sized for (cfg.max_batch may be lowered: OAKE_OPT_PASS_CROPS)
   bool text = false;          // text tower (oake_text_create): causal attention, token embedding
   int vocab = 0;
   float* tok_emb = nullptr;   // [vocab, width] fp32 (text)
@@ -338,7 +339,7 @@ void oake_destroy(oake_handle* h) {
   for (auto& l : h->layers) {
     void* lp[] = {l.ln1_g, l.ln1_b, l.ln2_g, l.ln2_b, l.in_w, l.out_w, l.fc_w, l.proj_w,
                   l.in_b, l.out_b, l.fc_b, l.proj_b, l.in_w32, l.fc_w32, l.in_wf, l.fc_wf,
-                  l.in_cs, l.fc_cs, l.in_bf, l.fc_bf};
+                  l.in_cs, l.fc_cs, l.in_bf, l.fc_bf, l.out_wp};
     for (void* p : lp)
       if (p) (void)hipFree(p);
   }
@@ -428,6 +429,7 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
     }
   }
 
+  h->pass_cap = c.max_batch;
   const size_t C = c.width, F = c.mlp_dim, E = c.embed_dim, L = h->tokens, B = c.max_batch;
   int rc = OAKE_OK;
   auto A = [&](void** p, size_t bytes) {
@@ -467,7 +469,6 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
       A((void**)&l.fc_cs, F * 4);
       A((void**)&l.in_bf, 3 * C * 4);
       A((void**)&l.fc_bf, F * 4);
-      if (!text && attn_out_supported((int)std::min<size_t>(L, 64), c.heads, c.width)) A(&l.out_wp, C * C * e16());
     }
   }
   // (every tensor that goes through the fp32 staging buffer: conv1, c_fc / c_proj, in_proj, the positional
@@ -638,10 +639,6 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
       HIP_TRY(h, hipStreamSynchronize(0));
     } else if (leaf == "attn.out_proj.weight") {
       W16(w.out_w, C * C);
-      if (w.out_wp) {
-        HIP_TRY(h, launch_permute_out_w(h->dt16, w.out_w, w.out_wp, 0));
-        HIP_TRY(h, hipStreamSynchronize(0));
-      }
     }
     else if (leaf == "attn.out_proj.bias") F32(w.out_b, C);
     else if (leaf == "mlp.c_fc.weight") {
@@ -852,12 +849,14 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   const int Lp = L;  // (the profile quotes ALGORITHMIC attention FLOPs, 4 L^2 d per head: padded key / query tiles are not work)
   // L <= 64 on the 16-bit residual stream (encode_image, blocks mode): attention + out_proj + residual + the row
   // statistics of the next LayerNorm in one kernel, one workgroup per image; `att` is never written (attn_out.hip)
+#if OAKE_LAB
   if (h->fuse_attn_out && h->stat_fused && !h->text && w.out_wp && attn_out_supported(L, h->cfg.heads, C)) {
     RUNK(h, s, "attn_out", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64 + 2.0 * T * C * C, (double)T * 5 * C * 2,
          launch_attn_out(h->dt16, h->qkv, w.out_wp, w.out_b, h->x, h->rowpart, nb, L, s));
     h->nparts = C / 64;
     return mlp_rows(h, s, w, 0, T, "", true);
   }
+#endif
   RUNK(h, s, "attention", 4.0 * nb * h->cfg.heads * (double)Lp * Lp * 64, (double)T * 4 * C * 2,
       launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s, nullptr, nullptr, 0,
                        nullptr, &h->opts));
@@ -1732,6 +1731,12 @@ int oake_debug_attn_out(const void* d_qkv, const void* d_w, const float* d_bias,
 
 int oake_debug_attn_out_trace(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x, float* d_rowpart,
                               int n, int l, int heads, int dtype16, void* d_trace, int repeats, void* stream) {
+#if !OAKE_LAB
+  // (the kernel lost its A/B — DESIGN.md §9.R4 item 4 — and lives in liboake_hip_lab.so only)
+  (void)d_qkv; (void)d_w; (void)d_bias; (void)d_x; (void)d_rowpart; (void)n; (void)l; (void)heads; (void)dtype16;
+  (void)d_trace; (void)repeats; (void)stream;
+  return OAKE_ERR_UNSUPPORTED;
+#else
   const int C = heads * 64;
   if (!d_qkv || !d_w || !d_bias || !d_x || !d_rowpart || n < 0) return OAKE_ERR_INVALID;
   if (!attn_out_supported(l, heads, C)) return OAKE_ERR_UNSUPPORTED;
@@ -1745,6 +1750,7 @@ int oake_debug_attn_out_trace(const void* d_qkv, const void* d_w, const float* d
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(wp);
   return dbg(e);
+#endif
 }
 
 int oake_debug_tr_read(const uint16_t* d_in, uint16_t* d_out, void* stream) {
@@ -1822,7 +1828,32 @@ int oake_set_option(oake_handle* h, int option, int value) {
       if (value < 0 || value > 4096) return fail(h, OAKE_ERR_INVALID, "cu_count must be in 0 .. 4096");
       h->opts.cu_count = value;
       return OAKE_OK;
-    case OAKE_OPT_FUSE_ATTN_OUT: h->fuse_attn_out = value ? 1 : 0; return OAKE_OK;
+    case OAKE_OPT_FUSE_ATTN_OUT:
+#if OAKE_LAB
+      // the permuted copies of W_out (C x C 16-bit per layer) exist only once the option has been switched on,
+      // and only where the kernel can run (the REAL sequence length: never at L = 197)
+      if (value && !h->text && h->xdt != DT_F32 && attn_out_supported(h->tokens, h->cfg.heads, h->cfg.width)) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        const size_t C = h->cfg.width;
+        for (auto& l : h->layers)
+          if (!l.out_wp) {
+            HIP_TRY(h, hipMalloc(&l.out_wp, C * C * 2));
+            HIP_TRY(h, launch_permute_out_w(h->dt16, l.out_w, l.out_wp, 0));
+          }
+        HIP_TRY(h, hipStreamSynchronize(0));
+      }
+      h->fuse_attn_out = value ? 1 : 0;
+      return OAKE_OK;
+#else
+      if (value) return fail(h, OAKE_ERR_INVALID, "fuse_attn_out: the fused attention + out_proj kernel is in "
+                             "liboake_hip_lab.so only (measured slower: DESIGN.md 9.R4 item 4)");
+      return OAKE_OK;
+#endif
+    case OAKE_OPT_PASS_CROPS:
+      if (h->text) return fail(h, OAKE_ERR_INVALID, "pass_crops: vision handles only");
+      if (value < 1) return fail(h, OAKE_ERR_INVALID, "pass_crops must be >= 1");
+      h->cfg.max_batch = std::min(value, h->pass_cap);  // (a bound: never above what the workspace was created for)
+      return OAKE_OK;
     default: return fail(h, OAKE_ERR_INVALID, "unknown option " + std::to_string(option));
   }
 }
@@ -1837,6 +1868,7 @@ int oake_get_option(const oake_handle* h, int option, int* value) {
     case OAKE_OPT_PATCH_DIRECT: *value = h->patch_direct; return OAKE_OK;
     case OAKE_OPT_CU_COUNT: *value = h->opts.cu_count; return OAKE_OK;
     case OAKE_OPT_FUSE_ATTN_OUT: *value = h->fuse_attn_out; return OAKE_OK;
+    case OAKE_OPT_PASS_CROPS: *value = h->cfg.max_batch; return OAKE_OK;
     default: return OAKE_ERR_INVALID;
   }
 }

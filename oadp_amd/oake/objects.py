@@ -213,14 +213,24 @@ class Validator(BaseValidator[Batch]):
             objects = self._to_device(objects)
         embs = []
         # On the GPU the flush goes down in ONE call: the library cuts it into equal encoder passes of at most
-        # min(mini_batch_size, ~25.6 k token rows) crops (csrc/api.hip), which is what mini_batch_size is for in the
-        # reference — a memory bound; a crop's embedding depends on its pass only through the rounding of the last
-        # layer's object-token GEMMs (tests/test_encoder_gpu.py::test_pass_cap_and_equal_passes_are_invisible).
+        # min(mini_batch_size, clip.load's max_batch, ~25.6 k token rows / OAKE_PASS_ROWS) crops — `mini_batch_size` is
+        # a memory bound in the reference and stays one here (visual.pass_limit -> OAKE_OPT_PASS_CROPS); a crop's
+        # embedding depends on its pass only through the rounding of the last layer's object-token GEMMs
+        # (tests/test_encoder_gpu.py::test_pass_cap_and_equal_passes_are_invisible).
+        visual = self._model.visual
+        if objects.is_cuda and hasattr(type(visual), 'pass_limit') and visual.pass_limit != self._mini_batch_size:
+            visual.pass_limit = self._mini_batch_size
         step = objects.shape[0] if objects.is_cuda and objects.shape[0] else self._mini_batch_size
         for i in range(math.ceil(objects.shape[0] / step)):
             sl = slice(i * step, (i + 1) * step)
             embs.append(self._model.visual(objects[sl], masks[sl], normalize=True, out_dtype=torch.float16))
         on_gpu = bool(embs) and embs[0].is_cuda
+        if on_gpu and not getattr(self, '_pass_logged', False) and hasattr(visual, 'get_option'):
+            self._pass_logged = True  # the effective pass size decides the output's last-bit rounding: say what it is
+            print(f'[{self.name}] encoder passes of at most {visual.get_option("pass_crops")} crops '
+                  f'(mini_batch_size {self._mini_batch_size}, max_batch {getattr(visual, "max_batch", None)}, '
+                  f'OAKE_PASS_ROWS {os.environ.get("OAKE_PASS_ROWS", "25600 (default)")}); flush of {objects.shape[0]} crops '
+                  f'in one native call', flush=True)
         # one device -> host copy per flush, left in flight while the next flush is prepared (base._flush)
         host = self._to_host(torch.cat(embs)) if embs else None
         meta = [(b.bboxes.shape[0], b.bboxes.half(), b.objectness.half()) for b in batches]

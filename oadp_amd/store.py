@@ -3,6 +3,7 @@ DRY_RUN (quick integrity check), CUDA / CPU (device presence)."""
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 
@@ -70,7 +71,8 @@ def shard_device_index(gpus: int, env=None) -> int:
 
 
 def cpu_slice(local_rank: int, local_world: int, cpus: list[int]) -> list[int]:
-    """Contiguous share of the host's logical CPUs for one of `local_world` ranks on this node."""
+    """Contiguous share of the host's logical CPUs for one of `local_world` ranks on this node (the fallback when
+    sysfs says nothing about the topology)."""
     n = len(cpus)
     if local_world <= 1 or n < local_world:
         return list(cpus)
@@ -78,27 +80,146 @@ def cpu_slice(local_rank: int, local_world: int, cpus: list[int]) -> list[int]:
     return list(cpus[lo:hi])
 
 
-def pin_cpus(env=None) -> list[int] | None:
-    """Per-rank CPU affinity for a multi-rank node: rank i of the node's N ranks (LOCAL_RANK / LOCAL_WORLD_SIZE, or
-    the OAKE_SHARD pair) keeps the i-th contiguous N-th of the CPUs this process may run on — a rank's host side
-    (file reads, Huffman threads, index math, .pth writers: ~11 cores per rank at full rate)
-    then stays on its own cores and caches instead of migrating across a 128-256-thread host.  OAKE_CPU_AFFINITY=0
-    switches it off.  Returns the CPUs kept (None: nothing done)."""
+def _parse_cpulist(text: str) -> list[int]:
+    """sysfs cpulist syntax: "0-63,128-191"."""
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _fmt_cpulist(cpus: list[int]) -> str:
+    runs, cpus = [], sorted(cpus)
+    for c in cpus:
+        if runs and c == runs[-1][1] + 1:
+            runs[-1][1] = c
+        else:
+            runs.append([c, c])
+    return ','.join(f'{a}-{b}' if b > a else f'{a}' for a, b in runs)
+
+
+def _read(path: str) -> str | None:
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def local_ranks(env=None) -> tuple[int, int] | None:
+    """(local rank, ranks on THIS host) — only where that is actually known: LOCAL_RANK + LOCAL_WORLD_SIZE (torchrun
+    exports both), or OAKE_SHARD=r/W together with an explicit OAKE_LOCAL_SHARDS=n (n shards of the W run on this
+    host; local rank = r mod n).  A lone `OAKE_SHARD=0/8` process, a one-process-per-node array job, or a launcher
+    that exports only the global WORLD_SIZE returns None: slicing the host by a count that is not this host's would
+    make the rank host-bound on 1/W of the cores (advisor r04)."""
+    env = os.environ if env is None else env
+    if 'LOCAL_RANK' in env and env.get('LOCAL_WORLD_SIZE'):
+        return int(env['LOCAL_RANK']), int(env['LOCAL_WORLD_SIZE'])
+    shard = parse_shard(env)
+    if shard and env.get('OAKE_LOCAL_SHARDS'):
+        n = int(env['OAKE_LOCAL_SHARDS'])
+        if n >= 1:
+            return shard[0] % n, n
+    return None
+
+
+def gpu_pci_addresses() -> list[str] | None:
+    """PCI addresses ("dddd:bb:dd.f") of the visible GPUs in HIP device order, or None without a HIP device.
+    (/sys/class/drm/card<i> is NOT in HIP order, and a container sees every card's node: the PCI address is the key.)"""
+    if not torch.cuda.is_available():
+        return None
+    out = []
+    for i in range(torch.cuda.device_count()):
+        p = torch.cuda.get_device_properties(i)
+        try:
+            out.append(f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0')
+        except AttributeError:
+            return None
+    return out
+
+
+def plan_cpus(local_rank: int, local_world: int, allowed: list[int], gpu_pci: list[str] | None = None,
+              sysfs: str = '/sys') -> tuple[list[int], str]:
+    """The CPUs rank `local_rank` of a node's `local_world` ranks should run on, and how they were chosen.
+
+    Topology-aware: rank r drives GPU r mod #GPUs; that GPU's NUMA node is read from
+    <sysfs>/bus/pci/devices/<addr>/numa_node and the node's CPUs from <sysfs>/devices/system/node/node<n>/cpulist;
+    the node's CPUs (those this process may run on) are split among the ranks whose GPUs share the node, whole
+    cores at a time — SMT siblings (<sysfs>/devices/system/cpu/cpu<c>/topology/thread_siblings_list) stay together,
+    whatever the numbering (siblings at +N/2 is the usual one).  On a two-socket host ranks 4-7 then sit on the
+    socket that owns GPUs 4-7, which a split of the logical CPU ids by rank does not give.  Where sysfs is silent
+    (no numa_node, node -1, no cpulist): the contiguous slices of `cpu_slice`."""
+    allowed = sorted(allowed)
+    if local_world <= 1:
+        return allowed, 'single rank: affinity unchanged'
+    fallback = (cpu_slice(local_rank % local_world, local_world, allowed), 'contiguous slice of the allowed CPUs')
+    if not gpu_pci:
+        return fallback
+    ng = len(gpu_pci)
+
+    def node_of(addr: str) -> int | None:
+        t = _read(f'{sysfs}/bus/pci/devices/{addr}/numa_node')
+        try:
+            n = int(t) if t is not None else -1
+        except ValueError:
+            n = -1
+        return n if n >= 0 else None
+
+    nodes = [node_of(a) for a in gpu_pci]
+    mine = nodes[local_rank % ng]
+    if mine is None:
+        return fallback
+    t = _read(f'{sysfs}/devices/system/node/node{mine}/cpulist')
+    if not t:
+        return fallback
+    node_cpus = [c for c in _parse_cpulist(t) if c in set(allowed)]
+    sharing = [r for r in range(local_world) if nodes[r % ng] == mine]
+    if not node_cpus or len(node_cpus) < len(sharing):
+        return fallback
+    # whole cores: a core = the set of its hardware threads that are in node_cpus
+    seen, cores = set(), []
+    for c in node_cpus:
+        if c in seen:
+            continue
+        sib = _read(f'{sysfs}/devices/system/cpu/cpu{c}/topology/thread_siblings_list')
+        grp = [s for s in (_parse_cpulist(sib) if sib else [c]) if s in set(node_cpus) and s not in seen] or [c]
+        seen.update(grp)
+        cores.append(sorted(grp))
+    k, m = sharing.index(local_rank), len(sharing)
+    if len(cores) < m:
+        return fallback
+    part = cores[k * len(cores) // m:(k + 1) * len(cores) // m]
+    keep = sorted(c for core in part for c in core)
+    return keep, f'NUMA node {mine} of GPU {local_rank % ng} ({gpu_pci[local_rank % ng]}), share {k + 1} of {m}, whole cores'
+
+
+def pin_cpus(env=None, gpu_pci: list[str] | None = None, sysfs: str = '/sys', apply: bool = True) -> list[int] | None:
+    """Per-rank CPU affinity for a multi-rank node: a rank's host side (file reads, Huffman threads, index math, .pth
+    writers: ~11 cores per rank at full rate) stays on cores of the socket its GPU hangs off
+    (`plan_cpus`) instead of migrating across a 128-256-thread host.  Done ONLY where the number of ranks on this host
+    is known (`local_ranks`); OAKE_CPU_AFFINITY=0 switches it off.  The CPUs kept are printed once per process.
+    Returns the CPUs kept (None: nothing done)."""
     env = os.environ if env is None else env
     if env.get('OAKE_CPU_AFFINITY', '1').lower() in ('0', 'false', 'no', 'off') or not hasattr(os, 'sched_setaffinity'):
         return None
-    shard = parse_shard(env)
-    if 'LOCAL_RANK' in env:
-        lr, lw = int(env['LOCAL_RANK']), int(env.get('LOCAL_WORLD_SIZE') or env.get('WORLD_SIZE') or 1)
-    elif shard and shard[1] <= 16:  # (a larger W spans nodes: how many shards share this host is not knowable here)
-        lr, lw = shard
-    else:
+    lr_lw = local_ranks(env)
+    if lr_lw is None or lr_lw[1] <= 1:
         return None
-    if lw <= 1:
-        return None
+    lr, lw = lr_lw
     cpus = sorted(os.sched_getaffinity(0))
-    keep = cpu_slice(lr % lw, lw, cpus)
+    if gpu_pci is None:
+        try:
+            gpu_pci = gpu_pci_addresses()
+        except Exception:  # noqa: BLE001 — topology is an optimisation, never a reason to fail a run
+            gpu_pci = None
+    keep, how = plan_cpus(lr % lw, lw, cpus, gpu_pci, sysfs)
     if not keep or len(keep) == len(cpus):
         return None
-    os.sched_setaffinity(0, keep)
+    if apply:
+        os.sched_setaffinity(0, keep)
+        print(f'[oake] local rank {lr}/{lw}: CPUs {_fmt_cpulist(keep)} ({len(keep)} of {len(cpus)}; {how}; '
+              f'OAKE_CPU_AFFINITY=0 to disable)', file=sys.stderr, flush=True)
     return keep

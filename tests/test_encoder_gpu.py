@@ -323,6 +323,47 @@ def test_pass_cap_and_equal_passes_are_invisible(cuda):
     _check(a[:4], ref, 1e-3, 1e-3)
 
 
+def test_pass_limit_is_a_memory_bound(cuda):
+    """The reference's `mini_batch_size` [REF oadp/oake/objects.py:321-331] bounds the crops of one encoder pass.  Here:
+    `visual.pass_limit` -> OAKE_OPT_PASS_CROPS lowers the library's cap (never raises it above what the handle's
+    workspace was created for), existing and later handles alike; visible in the number of launches; the features move
+    by the last layer's GEMM rounding only (advisor r04)."""
+    arch = dict(width=768, layers=2, heads=12, mlp_dim=3072, embed_dim=512)
+    sd = synthetic_state_dict(**arch)
+    model, _ = clip.load(sd, max_batch=48)
+    v = model.visual
+    x = synthetic_images(45, seed=8).to(cuda)
+    assert v.get_option('pass_crops') is None  # no handle yet
+    a = model.encode_image(x, normalize=True, out_dtype=torch.float32)
+    assert v.get_option('pass_crops') == 48
+
+    def qkv_launches():
+        v.profile(True)
+        out = model.encode_image(x, normalize=True, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        n = {p['name']: p['launches'] for p in v.profile_read()}.get('gemm_qkv', 0)
+        v.profile(False)
+        return out, n
+
+    _, one = qkv_launches()
+    v.pass_limit = 16
+    assert v.get_option('pass_crops') == 16
+    b, three = qkv_launches()  # 45 crops under a cap of 16: 3 passes of 15
+    assert three == 3 * one and one >= 1
+    torch.testing.assert_close(a, b, rtol=0, atol=3e-4)
+    v.pass_limit = 1000  # a bound: not above the 48 the workspace was sized for
+    assert v.get_option('pass_crops') == 48
+    v.pass_limit = 16
+    v.lane = 1  # a handle created later gets the same bound
+    try:
+        model.encode_image(x[:4])
+        assert v.get_option('pass_crops') == 16
+    finally:
+        v.lane = 0
+    with pytest.raises(Exception):
+        v.set_option('pass_crops', 0)
+
+
 def test_batches_beyond_1024_crops_per_pass(cuda, monkeypatch):
     """max_batch > 1024: the CLS rows of the last block (M = crops per pass) are then large enough for the
     persistent GEMM, which takes its LayerNorm statistics as per-row sums — decided per GEMM from the shape
@@ -526,11 +567,18 @@ def test_profiler_counts_stamped_and_seen_launches(cuda):
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
 def test_encode_image_fused_attention_out_proj(cuda, dtype, tol):
-    """The one-kernel attention + out_proj + residual (csrc/attn_out.hip, default where the persistent kernels run:
-    M > 1024 rows) against the oracle, against the two-launch form (fuse_attn_out = 0: same arithmetic up to the
-    summation order of out_proj's K dimension), and that it really is the path taken (profile slot names)."""
+    """The one-kernel attention + out_proj + residual (csrc/attn_out.hip; measured slower, so it lives in the LAB
+    library only: DESIGN.md 9.R4 item 4) against the oracle, against the two-launch form (fuse_attn_out = 0: same
+    arithmetic up to the summation order of out_proj's K dimension), and that it really is the path taken (profile
+    slot names).  The product library refuses the option."""
+    from oadp_amd import _lib
     sd = synthetic_state_dict()
-    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48)
+    prod, _ = clip.load(sd, compute_dtype=dtype, max_batch=4)
+    prod.encode_image(synthetic_images(2, seed=1).to(cuda))
+    with pytest.raises(_lib.OakeError, match='liboake_hip_lab'):
+        prod.visual.set_option('fuse_attn_out', 1)
+    prod.visual.set_option('fuse_attn_out', 0)  # switching it OFF is always valid
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48, lib=_lib.load_lab())
     x = synthetic_images(45, seed=145)
     ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
     v = model.visual

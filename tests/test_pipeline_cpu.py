@@ -501,6 +501,95 @@ def test_shard_parsing_device_choice_and_cpu_slices():
     assert cpu_slice(2, 3, list(range(10))) == [6, 7, 8, 9] and cpu_slice(0, 16, list(range(8))) == list(range(8))
 
 
+def _fake_sysfs(root, sockets=2, cores_per_socket=64, gpus=8, smt='offset'):
+    """A two-socket host as sysfs shows it: NUMA node s owns cores [s*64, (s+1)*64); SMT numbering either the usual
+    'offset' one (thread 1 of core c is CPU c + 128) or 'adjacent' (CPUs 2c, 2c+1); GPU g hangs off socket g // 4."""
+    ncores = sockets * cores_per_socket
+
+    def cpus_of(core):
+        return [core, core + ncores] if smt == 'offset' else [2 * core, 2 * core + 1]
+
+    for s in range(sockets):
+        cpus = sorted(c for core in range(s * cores_per_socket, (s + 1) * cores_per_socket) for c in cpus_of(core))
+        d = root / 'devices/system/node' / f'node{s}'
+        d.mkdir(parents=True)
+        runs, out = [], []
+        for c in cpus:
+            if runs and c == runs[-1][1] + 1:
+                runs[-1][1] = c
+            else:
+                runs.append([c, c])
+        (d / 'cpulist').write_text(','.join(f'{a}-{b}' for a, b in runs) + '\n')
+    for core in range(ncores):
+        for c in cpus_of(core):
+            d = root / f'devices/system/cpu/cpu{c}/topology'
+            d.mkdir(parents=True)
+            (d / 'thread_siblings_list').write_text(','.join(map(str, cpus_of(core))) + '\n')
+    addrs = []
+    for g in range(gpus):
+        a = f'0000:{0x05 + 0x10 * g:02x}:00.0'
+        d = root / 'bus/pci/devices' / a
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text(f'{g // (gpus // sockets)}\n')
+        addrs.append(a)
+    return addrs, 2 * ncores
+
+
+@pytest.mark.parametrize('smt', ['offset', 'adjacent'])
+def test_rank_cpus_follow_the_gpus_numa_node(tmp_path, smt):
+    """rank r's CPUs are a subset of the NUMA node its GPU hangs off, whole cores (SMT siblings
+    together), disjoint between ranks and covering the host — on a faked 2-socket x 4-GPU sysfs tree, with the usual
+    interleaved SMT numbering (socket 0 = CPUs 0-63 + 128-191), where a split of the logical ids by rank puts ranks
+    2, 3, 6, 7 on the wrong socket."""
+    from oadp_amd.store import _parse_cpulist, plan_cpus
+    addrs, ncpu = _fake_sysfs(tmp_path, smt=smt)
+    allowed = list(range(ncpu))
+    got = []
+    for r in range(8):
+        keep, how = plan_cpus(r, 8, allowed, addrs, sysfs=str(tmp_path))
+        node = set(_parse_cpulist((tmp_path / f'devices/system/node/node{r // 4}/cpulist').read_text()))
+        assert len(keep) == 32 and set(keep) <= node, (r, how)
+        assert f'NUMA node {r // 4}' in how and 'share' in how
+        for c in keep:  # whole cores
+            sib = _parse_cpulist((tmp_path / f'devices/system/cpu/cpu{c}/topology/thread_siblings_list').read_text())
+            assert set(sib) <= set(keep)
+        got.append(keep)
+    assert sorted(c for k in got for c in k) == allowed  # disjoint, nothing left idle
+    if smt == 'offset':  # the naive slice of logical ids is what this replaces: rank 2 -> CPUs 64-95 = socket 1
+        assert got[2] != list(range(64, 96)) and got[4][0] == 64
+    # 16 ranks on 8 GPUs (two processes per GPU): ranks r and r + 8 share GPU r's node, eight ranks per node
+    keep, how = plan_cpus(9, 16, allowed, addrs, sysfs=str(tmp_path))
+    assert len(keep) == 16 and 'share' in how and set(keep) <= set(_parse_cpulist(
+        (tmp_path / 'devices/system/node/node0/cpulist').read_text()))
+    # a cgroup that allows only some CPUs: the plan stays inside it
+    keep, _ = plan_cpus(5, 8, list(range(0, 256, 2)), addrs, sysfs=str(tmp_path))
+    assert keep and all(c % 2 == 0 for c in keep)
+    # sysfs silent (no numa_node files / node -1): the contiguous slices
+    keep, how = plan_cpus(2, 8, allowed, addrs, sysfs=str(tmp_path / 'nowhere'))
+    assert keep == list(range(64, 96)) and 'contiguous' in how
+    (tmp_path / 'bus/pci/devices' / addrs[2] / 'numa_node').write_text('-1\n')
+    assert plan_cpus(2, 8, allowed, addrs, sysfs=str(tmp_path))[0] == list(range(64, 96))
+    assert plan_cpus(2, 8, allowed, None)[0] == list(range(64, 96))
+
+
+def test_pinning_only_where_the_local_rank_count_is_known():
+    """Advisor r04 (medium): a lone OAKE_SHARD=0/8 process, a one-process-per-node array job or a launcher that exports
+    only the global WORLD_SIZE must NOT be sliced to 1/W of the host."""
+    from oadp_amd.store import local_ranks, pin_cpus
+    assert local_ranks({}) is None
+    assert local_ranks({'OAKE_SHARD': '0/8'}) is None
+    assert local_ranks({'LOCAL_RANK': '3', 'WORLD_SIZE': '16'}) is None          # ranks on THIS host unknown
+    assert local_ranks({'LOCAL_RANK': '3', 'LOCAL_WORLD_SIZE': '8', 'WORLD_SIZE': '16'}) == (3, 8)
+    assert local_ranks({'OAKE_SHARD': '11/16', 'OAKE_LOCAL_SHARDS': '8'}) == (3, 8)
+    assert pin_cpus({'OAKE_SHARD': '0/8'}, apply=False) is None
+    assert pin_cpus({'LOCAL_RANK': '0', 'LOCAL_WORLD_SIZE': '1'}, apply=False) is None
+    assert pin_cpus({'LOCAL_RANK': '1', 'LOCAL_WORLD_SIZE': '2', 'OAKE_CPU_AFFINITY': '0'}, apply=False) is None
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) >= 2:
+        keep = pin_cpus({'LOCAL_RANK': '1', 'LOCAL_WORLD_SIZE': '2'}, gpu_pci=[], apply=False)
+        assert keep == mine[len(mine) // 2:] and sorted(os.sched_getaffinity(0)) == mine  # planned, not applied
+
+
 def test_bpe_tokenizer_matches_an_independent_implementation(tmp_path):
     """oadp_amd/prompts/bpe.py against HuggingFace's CLIPTokenizer (slow, pure Python) on a SYNTHETIC merge table —
     CLIP's real vocabulary is not in this image; the algorithm (byte mapping, '</w>', greedy merges by rank, id
