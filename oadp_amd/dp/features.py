@@ -95,6 +95,22 @@ class PackAccessLayer(Mapping):
         blobs = [p for p in [root / f'{task_name}.pack'] if p.exists()] + sorted(root.glob(f'{task_name}.r*of*.pack'))
         if not blobs:
             raise FileNotFoundError(root / f'{task_name}.pack')
+        # one sweep = one world size: shards left over from a sweep with a different rank count (or a stale single
+        # blob beside fresh shards) would silently shadow or mix with the fresh features (first index entry wins)
+        import re
+        base = pathlib.PurePath(task_name).name
+        shards = [(p, m) for p in blobs if (m := re.fullmatch(re.escape(base) + r'\.r(\d+)of(\d+)\.pack', p.name))]
+        worlds = {int(m.group(2)) for _, m in shards}
+        if len(worlds) > 1 or (shards and len(shards) < len(blobs)):
+            raise ValueError(f'{root}: feature packs of more than one sweep for task {task_name!r} '
+                             f'({", ".join(p.name for p in blobs)}): remove the stale ones')
+        if worlds:
+            w = next(iter(worlds))
+            have = sorted(int(m.group(1)) for _, m in shards)
+            if have != list(range(w)):
+                import warnings
+                warnings.warn(f'{root}: task {task_name!r} has the shards of ranks {have} of {w} - the keys of the '
+                              f'missing ranks are absent', stacklevel=2)
         self._blobs = blobs
         self._index: dict[str, tuple[int, list]] = {}
         for i, blob in enumerate(blobs):

@@ -569,6 +569,10 @@ class BaseValidator(ABC, Generic[T]):
         try:
             self._run_loop(pending, crops)
         finally:
+            # (a run that raised leaves flushes in flight: their results belong to THIS run's writer and dataset and
+            # must not reach the next run()'s — val then train share the validator class, not the instance, but a
+            # caller may well re-run an instance)
+            self._inflight.clear()
             writer, self._writer = self._writer, None
             try:
                 writer.close()  # every file of this split is on disk (or the error is raised) here
@@ -647,7 +651,9 @@ class BaseValidator(ABC, Generic[T]):
         if override is not None:
             config.override(override)
 
-        distributed = get_world_size() > 1
+        # (OAKE_FORCE_DIST=1: a process group even at world size 1 — the RCCL calls of the multi-rank path executed on a
+        # 1-GPU box, tests/test_rccl_n1_gpu.py; needs the launcher's RANK / WORLD_SIZE / MASTER_* variables)
+        distributed = get_world_size() > 1 or os.environ.get('OAKE_FORCE_DIST', '') not in ('', '0')
         pin_cpus()  # a rank of a multi-rank node keeps its share of the host's cores (OAKE_CPU_AFFINITY=0: off)
         if Store.CUDA:
             # LOCAL_RANK under a launcher; shard r of OAKE_SHARD=r/W without one

@@ -268,3 +268,39 @@ def test_sharded_packs_and_a_killed_writer(tmp_path, monkeypatch):
     r = PackAccessLayer(str(tmp_path / 'k'), 'train2017')
     assert len(r) == 5 and torch.equal(r['000000000009'], torch.full((3,), 9.0).half())
     assert torch.equal(r['000000000001'], torch.full((3,), 1.0).half())
+
+
+def test_pack_layer_refuses_shards_of_two_sweeps(tmp_path):
+    """Advisor r04: shards left over from a sweep with another world size (or a stale single blob beside fresh
+    shards) must not silently shadow fresh features; an incomplete shard set warns."""
+    import warnings
+    from oadp_amd.packfile import PackWriter, blob_path
+    out = tmp_path / 'globals' / 'train2017'
+    out.parent.mkdir(parents=True)
+
+    def write(rank, world, keys):
+        w = PackWriter(blob_path(out, rank, world))
+        for k in keys:
+            w.submit(torch.full((4,), float(k)).half(), out / f'{k:012d}.pth')
+        w.close()
+
+    write(0, 2, [0, 2])
+    write(1, 2, [1, 3])
+    layer = PackAccessLayer(str(tmp_path / 'globals'), 'train2017')
+    assert sorted(layer) == [f'{k:012d}' for k in range(4)] and layer['000000000003'][0].item() == 3
+    write(0, 4, [0])  # a relaunch with another world size
+    with pytest.raises(ValueError, match='more than one sweep'):
+        PackAccessLayer(str(tmp_path / 'globals'), 'train2017')
+    for f in (tmp_path / 'globals').glob('train2017.r0of4.pack*'):
+        f.unlink()
+    write(0, 1, [7])  # a stale single blob beside the shards
+    with pytest.raises(ValueError, match='more than one sweep'):
+        PackAccessLayer(str(tmp_path / 'globals'), 'train2017')
+    for f in (tmp_path / 'globals').glob('train2017.pack*'):
+        f.unlink()
+    for f in (tmp_path / 'globals').glob('train2017.r1of2.pack*'):
+        f.unlink()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        layer = PackAccessLayer(str(tmp_path / 'globals'), 'train2017')
+    assert sorted(layer) == ['000000000000', '000000000002'] and any('missing ranks' in str(x.message) for x in w)

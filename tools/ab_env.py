@@ -14,7 +14,7 @@ one = {label: [] for label, _ in configs}
 extra = os.environ.get('AB_BENCH_ARGS', '--no-cpu-baseline --no-modes --steps 40').split()
 for r in range(rounds):
     for label, env in configs:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *extra], env=dict(os.environ, **env),
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *extra], env=dict(os.environ, OAKE_BENCH_FULL_LINE='1', **env),
                              capture_output=True, text=True)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
         if not line:

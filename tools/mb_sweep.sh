@@ -1,3 +1,4 @@
+export OAKE_BENCH_FULL_LINE=1
 set -x
 mkdir -p gpurun_out/mb
 for r in 1 2; do
