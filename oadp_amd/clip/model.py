@@ -296,7 +296,7 @@ class VisionTransformer(_HookPoint):
 
     def get_option(self, name: str) -> int | None:
         """``oake_get_option`` on the current lane's handle (None before the first call created it)."""
-        h = self.handle
+        h = self._handle
         if h is None:
             return None
         v = C.c_int(0)

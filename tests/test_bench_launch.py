@@ -64,7 +64,7 @@ def test_modes_produce_a_contract_line(mode, extra):
     assert sus['live'] and 1000 < sus['random_operands'] <= sus['zero_operands'] * 1.02 < 2700
     assert 0 < line['mfma_sustained_frac_e2e'] < 1 and 0 < rf['frac_of_board_random'] < 1
     # the calibration a reader needs sits in `roofline` itself; the per-kernel tables are in the side file
-    assert rf['sum_le_step'] and rf['kernels_sum_ms'] <= rf['one_lane_step_ms'] * 1.005
+    assert rf['sum_le_stamped_wall'] and 0.8 < rf['sum_over_step'] < 1.1  # (tiny config: ratio only loosely bound)
     assert len(json.dumps(line)) < 7000 and line['detail'] and (ROOT / line['detail']).exists()
     full = json.loads((ROOT / line['detail']).read_text())
     assert full['value'] == line['value'] and full['kernels'] and full['roofline']['sustained']['live']

@@ -81,7 +81,9 @@ def test_rank0_share_globals_blocks_at_size(cuda, tmp_path, vit_b32):
         crops, got = [], []
         for i in ids:
             pil = PIL.Image.open(root / 'train2017' / f'{i:012d}.jpg').convert('RGB')
-            crops.append(torch.from_numpy(crops_ref.preprocess_ref(pil)))
+            # globals mode's transform is clip.load_default(True) [REF oadp/oake/globals.py:47]: with the shipped
+            # fork setting (oadp_amd/clip/settings.py, load_default_true='squash') Resize((224, 224)) without a crop
+            crops.append(torch.from_numpy(crops_ref.preprocess_ref(pil.resize((224, 224), PIL.Image.BICUBIC))))
             t = torch.load(root / 'oake' / 'globals' / 'train2017' / f'{i:012d}.pth', 'cpu')
             assert t.dtype == torch.float16 and t.shape == (512,)
             got.append(t)
