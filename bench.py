@@ -596,7 +596,7 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
         # block for every token, as the reference does; OAKE_GEMM_VARIANT forces a GEMM tile configuration.
         for env, opt in (('OAKE_GEMM_VARIANT', 'gemm_variant'), ('OAKE_CLS_LAST', 'cls_last'),
                          ('OAKE_ATTN_VARIANT', 'attention_variant'), ('OAKE_PATCH_DIRECT', 'patch_direct'),
-                         ('OAKE_GEMM_PANEL', 'gemm_panel')):
+                         ('OAKE_GEMM_PANEL', 'gemm_panel'), ('OAKE_FUSE_QKV_ATTN', 'fuse_qkv_attn')):
             if env in os.environ:
                 model.visual.set_option(opt, int(os.environ[env]))
         work.build(model)

@@ -323,6 +323,11 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               out_proj weights stream through each CU's 64 B/clk vector-memory path once per
  *                               image): the kernel is in the lab build liboake_hip_lab.so only; the
  *                               production library answers OAKE_ERR_INVALID to a non-zero value.  Default 0.
+ *   OAKE_OPT_FUSE_QKV_ATTN      sequences of at most 53 tokens on a 16-bit residual stream (encode_image at 224^2 / patch
+ *                               32, blocks mode): ln_1 + attn.in_proj + softmax(q k^T) v of a layer run as ONE persistent
+ *                               kernel — a tile is (three images, one head), the q | k | v values go from the MFMA
+ *                               accumulators through LDS into the attention and never reach memory (csrc/qkv_attn.hip).
+ *                               Same 16-bit q / k / v values as the two-launch form.  [REF oadp/oake/globals.py:57]
  *   OAKE_OPT_PASS_CROPS         crops per internal encoder pass (vision handles).  get: the cap in force — what
  *                               oake_create derived from cfg.max_batch and the ~25 600-token-row target
  *                               (OAKE_PASS_ROWS).  set: a bound >= 1; the cap becomes min(value, the cap the handle
@@ -338,7 +343,8 @@ enum {
   OAKE_OPT_PATCH_DIRECT = 5,
   OAKE_OPT_CU_COUNT = 6,
   OAKE_OPT_FUSE_ATTN_OUT = 7,
-  OAKE_OPT_PASS_CROPS = 8
+  OAKE_OPT_PASS_CROPS = 8,
+  OAKE_OPT_FUSE_QKV_ATTN = 9
 };
 OAKE_API int oake_set_option(oake_handle* h, int option, int value);
 OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);

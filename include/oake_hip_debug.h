@@ -34,6 +34,14 @@ OAKE_API int oake_debug_gemm16(const void* d_a, const void* d_w, const float* d_
 OAKE_API int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gamma,
                          const float* d_beta, const float* d_bias, void* d_c, int m, int n, int k,
                          int dtype16, int gelu, void* stream);
+/* out16[n_img*l, heads*64] = softmax(q k^T) v per (image, head) with (q | k | v) = LayerNorm(x) W^T + bias rounded to 16
+ * bits, as ONE kernel (csrc/qkv_attn.hip: the q / k / v values never reach memory); x 16-bit [n_img*l, heads*64], W fp32
+ * [3*heads*64, heads*64] (q rows pre-scaled by the caller), l <= 53 else OAKE_ERR_UNSUPPORTED.  Synchronous.
+ * d_trace (or NULL): device buffer of 64 x 3 x 6 x 8 uint64 receiving the cycle stamps of the first blocks' tile phases
+ * (tools/qkv_attn_trace.py); repeats: launches of the kernel (timing loops). */
+OAKE_API int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
+                           const float* d_bias, void* d_out, int n_img, int l, int heads, int dtype16, void* d_trace,
+                           int repeats, void* stream);
 /* y = LayerNorm(x) over last dim `c` (eps 1e-5), x [rows,c] of x_dtype (OAKE_F32 or dtype16)
  * -> y 16-bit [rows,c]. */
 OAKE_API int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, const float* d_beta,

@@ -14,6 +14,7 @@ OAKE_OPT_PATCH_DIRECT = 5
 OAKE_OPT_CU_COUNT = 6
 OAKE_OPT_FUSE_ATTN_OUT = 7
 OAKE_OPT_PASS_CROPS = 8
+OAKE_OPT_FUSE_QKV_ATTN = 9
 ABI_VERSION = 3
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library
@@ -79,6 +80,7 @@ DEBUG_SIGNATURES = {
     'oake_debug_ln_gemm16': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     'oake_debug_layernorm': (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),
     'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
+    'oake_debug_ln_qkv_attn': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),
     'oake_debug_attention_objects': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_attn_out': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_attn_out_trace': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),

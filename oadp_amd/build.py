@@ -18,7 +18,7 @@ ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
-SOURCES = ['gemm.hip', 'attention.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'qkv_attn.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
 LAB_ONLY_SOURCES = ['attn_out.hip']  # kernels that lost their A/B: liboake_hip_lab.so only
 HEADERS = ['common.h', 'kernels.h', 'attention_head.inc', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'

@@ -168,7 +168,8 @@ class VisionTransformer(_HookPoint):
     OPTIONS = dict(cls_last=_lib.OAKE_OPT_CLS_LAST, gemm_variant=_lib.OAKE_OPT_GEMM_VARIANT,
                    gemm_panel=_lib.OAKE_OPT_GEMM_PANEL, attention_variant=_lib.OAKE_OPT_ATTENTION_VARIANT,
                    patch_direct=_lib.OAKE_OPT_PATCH_DIRECT, cu_count=_lib.OAKE_OPT_CU_COUNT,
-                   fuse_attn_out=_lib.OAKE_OPT_FUSE_ATTN_OUT, pass_crops=_lib.OAKE_OPT_PASS_CROPS)
+                   fuse_attn_out=_lib.OAKE_OPT_FUSE_ATTN_OUT, pass_crops=_lib.OAKE_OPT_PASS_CROPS,
+                   fuse_qkv_attn=_lib.OAKE_OPT_FUSE_QKV_ATTN)
 
     def set_option(self, name: str, value: int) -> None:
         """Per-model kernel-selection switch (``oake_set_option`` on every lane's handle, now and for

@@ -27,6 +27,9 @@
 #endif
 #include "../../include/oake_hip.h"
 #include "../../include/oake_hip_debug.h"
+#ifndef OAKE_FUSE_QKV_ATTN_DEFAULT
+#define OAKE_FUSE_QKV_ATTN_DEFAULT 1  // (+2.2 % globals with two lanes, profiles/r05/ab_fuse_qkv_attn_*.log)
+#endif
 #include "kernels.h"
 
 namespace oake {
@@ -54,6 +57,9 @@ struct LayerW {
   void *in_wf = nullptr, *fc_wf = nullptr;
   float *in_cs = nullptr, *fc_cs = nullptr, *in_bf = nullptr, *fc_bf = nullptr;
   void* out_wp = nullptr;  // out_proj weight in attn_out_kernel's fragment order (attn_out.hip), or nullptr
+  // the folded in-projection in head-major row order (q | k | v per head) for qkv_attn_kernel, or nullptr
+  void* in_wfp = nullptr;
+  float *in_csp = nullptr, *in_bfp = nullptr;
 };
 
 struct ProfSlot {
@@ -89,6 +95,8 @@ struct oake_handle {
   int patch_direct = 1;       // conv1 reads 16-bit NCHW input directly (0 = always through im2col; A/B, tests)
   int fuse_attn_out = 0;      // L <= 64: attention + out_proj + residual in one kernel (csrc/attn_out.hip; measured
                               // slower than the two launches — 39 vs 36 us per layer — so opt-in: tests, A/B runs)
+  int fuse_qkv_attn = OAKE_FUSE_QKV_ATTN_DEFAULT;  // L <= 53: ln_1 + in_proj + attention in one kernel (csrc/qkv_attn.hip)
+  bool qkv_perm = false;      // LayerW::in_wfp / in_csp / in_bfp are current
 
   // weights
   void* conv_w = nullptr;     // [width, 3*P*P] 16-bit
@@ -339,7 +347,7 @@ void oake_destroy(oake_handle* h) {
   for (auto& l : h->layers) {
     void* lp[] = {l.ln1_g, l.ln1_b, l.ln2_g, l.ln2_b, l.in_w, l.out_w, l.fc_w, l.proj_w,
                   l.in_b, l.out_b, l.fc_b, l.proj_b, l.in_w32, l.fc_w32, l.in_wf, l.fc_wf,
-                  l.in_cs, l.fc_cs, l.in_bf, l.fc_bf, l.out_wp};
+                  l.in_cs, l.fc_cs, l.in_bf, l.fc_bf, l.out_wp, l.in_wfp, l.in_csp, l.in_bfp};
     for (void* p : lp)
       if (p) (void)hipFree(p);
   }
@@ -839,6 +847,27 @@ int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, c
   return gemm(h, s, n_pr.c_str(), resid, hb, w.proj_w, w.proj_b, xr, M, C, F, C, nullptr, nullptr, r0);
 }
 
+// the head-major copies of the folded in-projection (qkv_attn.hip): made on the first pass that takes the fused path
+int ensure_qkv_perm(oake_handle* h) {
+  if (h->qkv_perm) return OAKE_OK;
+  const size_t C = h->cfg.width;
+  for (auto& w : h->layers) {
+    if (!w.in_wfp) HIP_TRY(h, hipMalloc(&w.in_wfp, 3 * C * C * 2));
+    if (!w.in_csp) HIP_TRY(h, hipMalloc((void**)&w.in_csp, 3 * C * 4));
+    if (!w.in_bfp) HIP_TRY(h, hipMalloc((void**)&w.in_bfp, 3 * C * 4));
+    HIP_TRY(h, launch_permute_qkv(h->dt16, w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
+  }
+  HIP_TRY(h, hipStreamSynchronize(0));
+  h->qkv_perm = true;
+  return OAKE_OK;
+}
+
+// true when the main token stream of this pass takes ln_1 + in_proj + attention as ONE kernel (qkv_attn.hip)
+bool fuses_qkv_attn(const oake_handle* h, int nb) {
+  return h->fuse_qkv_attn && h->stat_fused && !h->text && h->xdt != DT_F32 &&
+         qkv_attn_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
+}
+
 int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_only) {
   return in_proj_rows(h, s, w, 0, T, kv_only, kv_only ? "gemm_kv" : "gemm_qkv");
 }
@@ -862,6 +891,19 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
                        nullptr, &h->opts));
   return mlp_rows(h, s, w, 0, T, "");
 }
+
+// ln_1 + in_proj + attention of the main token stream as one kernel, then out_proj + MLP
+int main_qkv_attn(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
+  const int C = h->cfg.width, L = h->cur_len, T = nb * L;
+  int np = 0, rc;
+  if ((rc = ln_stats(h, s, reinterpret_cast<const char*>(h->x), 0, T, 3 * C, C, &np))) return rc;
+  if (np < 1 || !w.in_wfp) return fail(h, OAKE_ERR_STATE, "qkv_attn: no row statistics / permuted weights");
+  RUNK(h, s, "qkv_attn", 2.0 * T * 3 * C * C + 4.0 * nb * h->cfg.heads * (double)L * L * 64, 0.0,
+       launch_qkv_attn(h->dt16, h->x, w.in_wfp, w.in_bfp, w.in_csp, h->rowpart, np, h->att, nb, L, h->cfg.heads,
+                       &h->opts, s));
+  return mlp_rows(h, s, w, 0, T, "");
+}
+
 
 // ln_post over `nb` rows (x + i*row_stride) -> @ proj -> optional L2 normalise -> out
 int head(oake_handle* h, hipStream_t s, const void* x, int x_dtype, long row_stride, void* outp,
@@ -890,8 +932,12 @@ int check_ready(oake_handle* h) {
                                 F, C, 0));
     }
     HIP_TRY(h, hipStreamSynchronize(0));
+    h->qkv_perm = false;
   }
   h->folded = true;
+  if (h->fuse_qkv_attn && !h->text && h->xdt != DT_F32 && !h->qkv_perm &&
+      qkv_attn_supported(h->tokens, h->cfg.heads, h->cfg.width, 1))
+    return ensure_qkv_perm(h);
   return OAKE_OK;
 }
 
@@ -1075,6 +1121,10 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
     for (int l = 0; l < c.layers; ++l) {
       const LayerW& w = h->layers[l];
       if (l + 1 < c.layers || !cls_last) {
+        if (fuses_qkv_attn(h, nb)) {
+          if ((rc = main_qkv_attn(h, s, w, nb))) return rc;
+          continue;
+        }
         if ((rc = main_in_proj(h, s, w, T, false))) return rc;
         if ((rc = main_block_tail(h, s, w, nb))) return rc;
         continue;
@@ -1704,6 +1754,34 @@ int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gam
   return dbg(e);
 }
 
+int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
+                           const float* d_bias, void* d_out, int n_img, int l, int heads, int dtype16, void* d_trace,
+                           int repeats, void* stream) {
+  const int C = heads * 64, n = 3 * C, m = n_img * l;
+  if (!d_x || !d_w32 || !d_gamma || !d_beta || !d_bias || !d_out || n_img < 1) return OAKE_ERR_INVALID;
+  if (!qkv_attn_supported(l, heads, C, n_img)) return OAKE_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  void *wf = nullptr, *wp = nullptr;
+  float *cs = nullptr, *bf = nullptr, *csp = nullptr, *bfp = nullptr, *part = nullptr;
+  hipError_t e = hipMalloc(&wf, (size_t)n * C * 2);
+  if (e == hipSuccess) e = hipMalloc(&wp, (size_t)n * C * 2);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&cs), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bf), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&csp), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bfp), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&part), (size_t)m * 32 * 4);
+  if (e == hipSuccess) e = launch_fold_ln(dtype16, d_w32, d_gamma, d_beta, d_bias, wf, cs, bf, n, C, s);
+  if (e == hipSuccess) e = launch_rowsums(d_x, dtype16, C, part, m, C, s);
+  if (e == hipSuccess) e = launch_permute_qkv(dtype16, wf, bf, cs, wp, bfp, csp, C, s);
+  for (int i = 0; i < (repeats < 1 ? 1 : repeats) && e == hipSuccess; ++i)
+    e = launch_qkv_attn(dtype16, d_x, wp, bfp, csp, part, 1, d_out, n_img, l, heads, &t_debug_opts, s,
+                        reinterpret_cast<unsigned long long*>(d_trace));
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(wf); (void)hipFree(wp); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(csp); (void)hipFree(bfp);
+  (void)hipFree(part);
+  return dbg(e);
+}
+
 int oake_debug_layernorm(const void* d_x, int x_dtype, const float* d_gamma, const float* d_beta,
                          void* d_y, int rows, int c, int dtype16, void* stream) {
   return dbg(launch_layernorm(dtype16, d_x, x_dtype, c, d_gamma, d_beta, d_y, rows, c,
@@ -1849,6 +1927,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
                              "liboake_hip_lab.so only (measured slower: DESIGN.md 9.R4 item 4)");
       return OAKE_OK;
 #endif
+    case OAKE_OPT_FUSE_QKV_ATTN: h->fuse_qkv_attn = value ? 1 : 0; return OAKE_OK;
     case OAKE_OPT_PASS_CROPS:
       if (h->text) return fail(h, OAKE_ERR_INVALID, "pass_crops: vision handles only");
       if (value < 1) return fail(h, OAKE_ERR_INVALID, "pass_crops must be >= 1");
@@ -1869,6 +1948,7 @@ int oake_get_option(const oake_handle* h, int option, int* value) {
     case OAKE_OPT_CU_COUNT: *value = h->opts.cu_count; return OAKE_OK;
     case OAKE_OPT_FUSE_ATTN_OUT: *value = h->fuse_attn_out; return OAKE_OK;
     case OAKE_OPT_PASS_CROPS: *value = h->cfg.max_batch; return OAKE_OK;
+    case OAKE_OPT_FUSE_QKV_ATTN: *value = h->fuse_qkv_attn; return OAKE_OK;
     default: return OAKE_ERR_INVALID;
   }
 }

@@ -164,6 +164,18 @@ hipError_t launch_permute_out_w(int dtype16, const void* w, void* wp, hipStream_
 hipError_t launch_attn_out(int dtype16, const void* qkv, const void* wperm, const float* bias, void* x,
                            float* rowpart, int n, int L, hipStream_t s, unsigned long long* trace = nullptr);
 
+// ---- LN-folded qkv in-projection + attention in one persistent kernel (qkv_attn.hip) ------------
+// Sequences of at most 53 tokens (three images per 160-row tile) on a 16-bit residual stream, 64-wide heads:
+// out [n*L, H*64] = softmax(q k^T) v with (q | k | v) = rstd * (x W'^T) + (-mean rstd) * colsum + bias' computed tile by
+// tile and never written.  wp / biasp / colsump = the folded in-projection in head-major row order
+// (launch_permute_qkv: row h * 192 + 64 m + j <- row m * C + 64 h + j); rowpart / nparts as for the LN-folded GEMMs.
+bool qkv_attn_supported(int L, int heads, int width, int n_img);
+hipError_t launch_permute_qkv(int dtype16, const void* w, const float* bias, const float* colsum, void* wp, float* biasp,
+                              float* colsump, int width, hipStream_t s);
+hipError_t launch_qkv_attn(int dtype16, const void* x, const void* wp, const float* biasp, const float* colsump,
+                           const float* rowpart, int nparts, void* out, int n_img, int L, int heads,
+                           const LaunchOpts* opts, hipStream_t s, unsigned long long* trace = nullptr);
+
 // ---- head tail ---------------------------------------------------------------------------
 // rows of [n, e] fp32 -> optional L2 normalise (F.normalize, eps 1e-12) -> out [n, e] (fp32 or f16)
 hipError_t launch_l2norm_rows(const float* in, void* out, int out_dtype, int normalize, int n, int e,

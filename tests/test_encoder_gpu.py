@@ -323,6 +323,41 @@ def test_pass_cap_and_equal_passes_are_invisible(cuda):
     _check(a[:4], ref, 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
+def test_encode_image_fused_qkv_attention(cuda, dtype, tol):
+    """ln_1 + in_proj + attention as one kernel per layer (csrc/qkv_attn.hip, OAKE_OPT_FUSE_QKV_ATTN) on the full
+    ViT-B/32: against the oracle, against the two-launch form (the same 16-bit q / k / v values: the features agree to
+    the rounding of different summation orders), that it really is the path taken (profile slot names), and that an
+    image's result does not depend on its position in its three-image tile or in the batch."""
+    sd = synthetic_state_dict()
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48)
+    x = synthetic_images(46, seed=146)  # 46 = 15 groups of three + one: a ragged last tile
+    ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
+    v = model.visual
+    xg = x.to(cuda)
+    model.encode_image(xg[:2])  # creates the handle
+    v.set_option('fuse_qkv_attn', 1)
+    v.profile(True)
+    fused = model.encode_image(xg, normalize=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    names = {p['name']: p['launches'] for p in v.profile_read() if p['launches'] > 0}
+    v.profile(False)
+    assert names.get('qkv_attn') == 11 and 'attention' not in names and 'gemm_qkv' not in names, names
+    _check(fused, ref, tol, tol)
+    v.set_option('fuse_qkv_attn', 0)
+    v.profile(True)
+    plain = model.encode_image(xg, normalize=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    names = {p['name']: p['launches'] for p in v.profile_read() if p['launches'] > 0}
+    v.profile(False)
+    assert 'qkv_attn' not in names and names.get('attention') == 11 and names.get('gemm_qkv') == 11, names
+    _check(plain, ref, tol, tol)
+    assert (fused - plain).abs().max().item() <= tol
+    v.set_option('fuse_qkv_attn', 1)
+    again = model.encode_image(xg.flip(0), normalize=True, out_dtype=torch.float32).flip(0)
+    assert (again - fused).abs().max().item() <= 3e-4  # (the last layer's small GEMMs pick tiles by row position)
+
+
 def test_pass_limit_is_a_memory_bound(cuda):
     """The reference's `mini_batch_size` [REF oadp/oake/objects.py:321-331] bounds the crops of one encoder pass.  Here:
     `visual.pass_limit` -> OAKE_OPT_PASS_CROPS lowers the library's cap (never raises it above what the handle's
@@ -341,11 +376,13 @@ def test_pass_limit_is_a_memory_bound(cuda):
         v.profile(True)
         out = model.encode_image(x, normalize=True, out_dtype=torch.float32)
         torch.cuda.synchronize()
-        n = {p['name']: p['launches'] for p in v.profile_read()}.get('gemm_qkv', 0)
+        d = {p['name']: p['launches'] for p in v.profile_read()}
+        n = d.get('qkv_attn', 0) + d.get('gemm_qkv', 0)  # one per full layer and pass (fused with the attention where M > 1024)
         v.profile(False)
         return out, n
 
     _, one = qkv_launches()
+    assert one == 1  # two layers, the last one runs for the CLS rows: one in-projection of all rows per pass
     v.pass_limit = 16
     assert v.get_option('pass_crops') == 16
     b, three = qkv_launches()  # 45 crops under a cap of 16: 3 passes of 15
@@ -584,6 +621,7 @@ def test_encode_image_fused_attention_out_proj(cuda, dtype, tol):
     v = model.visual
     xg = x.to(cuda)
     model.encode_image(xg[:2])  # creates the handle
+    v.set_option('fuse_qkv_attn', 0)  # (the production default fuses the OTHER side of the attention: csrc/qkv_attn.hip)
     v.set_option('fuse_attn_out', 1)
     v.profile(True)
     fused = model.encode_image(xg, normalize=True, out_dtype=torch.float32)

@@ -179,6 +179,54 @@ def _attention_ref(qkv, n, l, heads):
     return (p @ v).permute(0, 2, 1, 3).reshape(n * l, c)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('n,l,heads', [(3, 50, 12), (1, 50, 12), (2, 50, 12), (256, 50, 12), (7, 50, 3), (100, 50, 12),
+                                       (5, 53, 4), (4, 17, 3), (3, 1, 3), (9, 33, 12), (770, 50, 12)])
+def test_ln_qkv_attention_fused(lib, cuda, dtype, n, l, heads):
+    """csrc/qkv_attn.hip: ln_1 folded into attn.in_proj + softmax(q k^T) v as ONE persistent kernel (a tile = three
+    images x one head; q | k | v go from the accumulators through LDS into the attention) against the same chain in
+    fp32 torch from the same 16-bit x: LayerNorm -> in_proj -> ROUNDED to 16 bits (as the two-launch form stores it) ->
+    attention.  Shapes: full groups, a ragged last group (1 and 2 images), several tiles per block with different
+    heads (256 x 12 = 1032 tiles; 770 images = 3084 tiles: 12 per block), other sequence lengths and head counts."""
+    c = heads * 64
+    g = torch.Generator(device='cpu').manual_seed(n * 1000 + l * 10 + heads)
+    x = torch.randn(n * l, c, generator=g) * 1.5 + 0.3
+    x[:, 5] *= 12.0  # CLIP's residual stream has a few large-magnitude channels
+    x = x.to(dtype).to(cuda)
+    w = torch.randn(3 * c, c, generator=g) * (c ** -0.5)
+    w[:c] *= 0.35  # pre-scaled q rows: scores ~ N(0, 2.8^2), a peaky softmax
+    w = w.to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(c, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(c, generator=g)).to(cuda)
+    bias = (0.5 * torch.randn(3 * c, generator=g)).to(cuda)
+    out = torch.full((n * l + 3, c), 7.0, dtype=dtype, device=cuda)  # guard rows behind the last image
+    rc = lib.oake_debug_ln_qkv_attn(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+                                    out.data_ptr(), n, l, heads, DT[dtype], None, 1, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    # (a) the attention of the 16-bit q | k | v the two-launch form stores (oake_debug_ln_gemm16: same folded weights,
+    # same K order of the fp32 accumulation -> the same rounded values), in fp32 torch: attention-kernel tolerance
+    qkv16 = torch.empty(n * l, 3 * c, dtype=dtype, device=cuda)
+    assert lib.oake_debug_ln_gemm16(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+                                    qkv16.data_ptr(), n * l, 3 * c, c, DT[dtype], 0, _stream()) == 0
+    torch.cuda.synchronize()
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    torch.testing.assert_close(out[:n * l].float(), _attention_ref(qkv16, n, l, heads), rtol=tol, atol=tol)
+    # (b) the whole chain in fp32 torch: the 16-bit rounding of q / k / v (1 ulp either way) moves a peaky softmax
+    qkv = (torch.nn.functional.layer_norm(x.float(), (c,), gamma, beta, 1e-5) @ w.t() + bias).to(dtype)
+    ref = _attention_ref(qkv, n, l, heads)
+    err = (out[:n * l].float() - ref).abs()
+    assert err.max().item() < (0.05 if dtype == torch.float16 else 0.4) and err.mean().item() < (1.5e-3 if dtype == torch.float16 else 1.5e-2)
+    assert torch.equal(out[n * l:], torch.full((3, c), 7.0, dtype=dtype, device=cuda))  # nothing written past the rows
+
+
+def test_ln_qkv_attention_refuses_long_sequences(lib, cuda):
+    z = torch.zeros(64, device=cuda)
+    args = [z.data_ptr()] * 6
+    assert lib.oake_debug_ln_qkv_attn(*args, 1, 54, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lib.oake_debug_ln_qkv_attn(*args, 1, 197, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+
+
 # bit 2: K / V shared through LDS for l > 64; bit 4: persistent loader-wave kernel for l <= 64; bit 5 (63):
 # eight-wave blocks for l > 128 (197, 130, 300 below); bit 6 (95): whole K / V in LDS for 64 < l <= 208
 # bit 7 (159, the default): one block per head, one-pass softmax for 192 < l <= 208 (197 and the three seam shapes)
