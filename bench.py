@@ -204,8 +204,15 @@ class BlocksWork(_Work):
                          f'{self.crops} crops, encoder batches of {a.max_batch}; random-init weights')
 
     def step(self, model):
+        return self.back(model, self.front(model, model.visual.lane % len(self.buf)))
+
+    def back(self, model, buf):
         import torch
-        v, buf = model.visual, self.buf[model.visual.lane % len(self.buf)]
+        return model.encode_image(buf, normalize=True, out_dtype=torch.float16)
+
+    def front(self, model, slot):
+        import torch
+        v, buf = model.visual, self.buf[slot]
         ds = self.ds
         # host index math of the path (bboxes of every block, blocks.py:83-109) ...
         for im in self.images:
@@ -216,7 +223,7 @@ class BlocksWork(_Work):
         # ... pyramids + crops of the whole batch on the device (one native call), then the encoder
         v.blocks_batch(self.images, block_size=ds._r, max_stride=ds._s, rescale=ds._rescale,
                        out_dtype=torch.float16, out=buf)
-        return model.encode_image(buf, normalize=True, out_dtype=torch.float16)
+        return buf
 
     def cpu_baseline(self, seconds: float = 15.0) -> dict:
         """Reference-style CPU path of the same workload: PIL pyramid + crops + the fp32 oracle encoder."""
@@ -287,8 +294,19 @@ class ObjectsWork(_Work):
                          f'mini-batches of {a.max_batch}; {self.crops} crops per step; random-init weights')
 
     def step(self, model):
+        return self.back(model, self.front(model, 0))
+
+    def back(self, model, inp):
         import torch
-        v, ds, mb = model.visual, self.ds, self.args.max_batch
+        v, mb = model.visual, self.args.max_batch
+        objs, masks = inp
+        embs = [v(objs[i:i + mb], masks[i:i + mb], normalize=True, out_dtype=torch.float16)
+                for i in range(0, objs.shape[0], mb)]
+        return torch.cat(embs)
+
+    def front(self, model, slot):
+        import torch
+        v, ds = model.visual, self.ds
         boxes_per_image, masks = [], []
         for p in self.props:  # host index math of the path (objects.py:157-186): filter, expand, masks
             prop = p[:, :4]
@@ -299,16 +317,14 @@ class ObjectsWork(_Work):
             boxes_per_image.append(boxes)
         objs = v.crop_resize_normalize_batch(self.images, boxes_per_image, out_dtype=torch.float16)
         m = torch.cat(masks).half()  # 0/1: exact in fp16; up through a pinned slot, as objects.Validator does
-        slot, buf = self.pool.acquire(m.numel(), m.dtype)
+        slot, buf = self.pool.acquire(m.numel(), m.dtype)  # (shadows the lane slot: not used below)
         src = buf.view(m.shape)
         src.copy_(m)
         masks = src.to(self.dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pool.release_after(slot, ev)
-        embs = [v(objs[i:i + mb], masks[i:i + mb], normalize=True, out_dtype=torch.float16)
-                for i in range(0, objs.shape[0], mb)]
-        return torch.cat(embs)
+        return objs, masks
 
     def cpu_baseline(self, seconds: float = 15.0) -> dict:
         """Reference-style CPU path: PIL crops + the fp32 oracle dual-stream encoder, a few proposals."""
@@ -638,6 +654,39 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
         finally:
             model.visual.lane = 0
 
+    # OAKE_BENCH_ASYM=1 (blocks / objects, two lanes; A/B of VERDICT r04 next 5): the lanes split by STAGE instead of by
+    # step — lane 0 runs every step's front end (pyramid / crops / masks: HBM-bound integer work) one step ahead, lane 1
+    # every step's encoder (MFMA-bound): different bounding resources side by side instead of two encoders time-slicing
+    asym = (os.environ.get('OAKE_BENCH_ASYM', '') not in ('', '0') and n_lanes == 2 and not DRY_PLUMBING
+            and hasattr(work, 'front'))
+    if asym:
+        free_ev = [None, None]
+
+        def step():  # noqa: F811
+            k = step_no[0]
+            step_no[0] += 1
+            slot = k % 2
+            f_s, e_s = lane_streams
+            try:
+                model.visual.lane = 0
+                with torch.cuda.stream(f_s):
+                    if free_ev[slot] is not None:
+                        f_s.wait_event(free_ev[slot])  # the encoder has read this slot's crops (two steps ago)
+                    inp = work.front(model, slot)
+                    for t in (inp if isinstance(inp, tuple) else (inp,)):
+                        t.record_stream(e_s)
+                    ready = torch.cuda.Event()
+                    ready.record(f_s)
+                model.visual.lane = 1
+                with torch.cuda.stream(e_s):
+                    e_s.wait_event(ready)
+                    out = work.back(model, inp)
+                    free_ev[slot] = torch.cuda.Event()
+                    free_ev[slot].record(e_s)
+                return out
+            finally:
+                model.visual.lane = 0
+
     for _ in range(n_lanes):  # set-up, not a step of the contract: create every lane's handle (weights, buffers)
         out = step()
     sync()
@@ -771,7 +820,8 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
                        'backend': ctx['backend'] if dist else None, 'hip_streams': n_lanes,
                        'setup': (f'{n_lanes} handle-creation step(s) + {ramp_steps} untimed clock-ramp steps '
                                  f'({ramp_s} s, OAKE_BENCH_RAMP_S) before the {args.warmup} warm-up steps'),
-                       'cu_split': os.environ.get('OAKE_BENCH_CU_SPLIT') or None},
+                       'cu_split': os.environ.get('OAKE_BENCH_CU_SPLIT') or None,
+                       'lanes_by_stage': bool(asym) or None},
             'crops_per_sec': None if DRY_PLUMBING else round(crops_per_s, 1),
             # fraction of the 2.5 PFLOP/s data-sheet MFMA peak, end to end: on the FLOPs the library executes and
             # on the model's FLOPs per crop as SURVEY.md §8(d) defines them (the reference's execution)
