@@ -13,7 +13,7 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 
 def _run(args, env_extra, timeout=600):
     env = dict(os.environ, PYTHONPATH=str(ROOT), **env_extra)
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'OAKE_BENCH_FULL_LINE'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *args], capture_output=True, text=True,
                        env=env, timeout=timeout)

@@ -17,7 +17,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 SESSION="$(hostname)-$(date -u +%Y%m%dT%H%M%SZ)"
 { echo "session: $SESSION"; echo "head: $(cat .git/HEAD 2>/dev/null || echo n/a)"; rocm-smi --showproductname 2>/dev/null | grep -i -m2 "card series\|gfx" ; rocm-smi --showmaxpower --showpower 2>/dev/null | grep -i "power" ; } > $O/session.txt
 if [ "$TESTS" = "1" ]; then
-  python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+  env -u OAKE_BENCH_FULL_LINE python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 fi
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"
