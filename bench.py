@@ -159,9 +159,9 @@ class GlobalsWork(_Work):
 
         l2_normalize(encode_image_ref(self.sd, cfg, x[:8]))  # thread pool / allocator warm-up
         # torch's default pool (one thread per physical core) is not the fastest on a 128-core, two-socket host: the
-        # baseline is quoted at the best of {all, 1/2, 1/4} of the cores (one bs-32 batch each, after a warm batch)
+        # baseline is quoted at the best of {all, 1/2, 1/4, 1/8} of the cores (one bs-32 batch each, after a warm batch)
         all_threads, probe = torch.get_num_threads(), {}
-        for t in sorted({all_threads, max(1, all_threads // 2), max(1, all_threads // 4)}, reverse=True):
+        for t in sorted({all_threads, max(1, all_threads // 2), max(1, all_threads // 4), max(1, all_threads // 8)}, reverse=True):
             torch.set_num_threads(t)
             l2_normalize(encode_image_ref(self.sd, cfg, x[:32]))
             t0 = time.perf_counter()
