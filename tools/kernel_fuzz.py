@@ -3,7 +3,8 @@ to 30 000 (ragged tiles, one row, several tiles per persistent block), N a multi
 64 up to 3 072, f16 and bf16, the automatic kernel choice; bias / QuickGELU / LayerNorm-folded / residual epilogues
 incl. the per-slice row sums; attention with 1..6 items, 1..300 keys, 1..12 heads; attention with the objects-mode
 object token fused in (65..224 keys, half of the cases in attention_head_kernel's 193..208; random masks, one crop all
-foreground), both kernel forms the product carries.  usage: kernel_fuzz.py [n=200] [seed=0]"""
+foreground), both kernel forms the product carries; the fused ln_1 + in_proj + attention kernel (1..400 images, L <= 53,
+3..12 heads) against the two-launch form's 16-bit q | k | v.  usage: kernel_fuzz.py [n=200] [seed=0]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -38,7 +39,7 @@ for it in range(n_cases):
     bias = torch.randn(n, generator=g).to(dev)
     info = (m, n, k, str(dtype).split('.')[-1])
     tol = 3e-3 if dtype == torch.float16 else 2.5e-2
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     if kind == 0:    # bias / QuickGELU epilogues
         gelu = int(rng.integers(0, 2))
         c = torch.full((m, n), float('nan'), dtype=dtype, device=dev)
@@ -76,6 +77,32 @@ for it in range(n_cases):
         if rc: bad += 1; print('RC', rc, 'resid16', info); continue
         ref = x0.float() + a.float() @ w.float().t() + bias
         check('resid16', x, ref, 1.5 * tol, info)
+    elif kind == 5:  # ln_1 + in_proj + attention as one kernel (csrc/qkv_attn.hip): 1..400 images, L <= 53, 3..12 heads
+        nn_, L, heads = int(rng.integers(1, 401)), int(rng.integers(1, 54)), int(rng.integers(3, 13))
+        c_ = heads * 64
+        if nn_ * L * c_ > 20_000_000:
+            nn_ = max(1, 20_000_000 // (L * c_))
+        x = torch.randn(nn_ * L, c_, generator=g) * 1.5 + 0.3
+        x[:, int(rng.integers(0, c_))] *= 10.0
+        x = x.to(dtype).to(dev)
+        wq = torch.randn(3 * c_, c_, generator=g) * c_ ** -0.5
+        wq[:c_] *= 0.35
+        wq = wq.to(dev)
+        gamma = (1.0 + 0.3 * torch.randn(c_, generator=g)).to(dev)
+        beta = (0.2 * torch.randn(c_, generator=g)).to(dev)
+        bq = (0.5 * torch.randn(3 * c_, generator=g)).to(dev)
+        out = torch.zeros(nn_ * L, c_, dtype=dtype, device=dev)
+        rc = lib.oake_debug_ln_qkv_attn(x.data_ptr(), wq.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bq.data_ptr(),
+                                        out.data_ptr(), nn_, L, heads, DT[dtype], None, 1, s)
+        if rc: bad += 1; print('RC', rc, 'ln_qkv_attn', (nn_, L, heads)); continue
+        qkv16 = torch.empty(nn_ * L, 3 * c_, dtype=dtype, device=dev)  # the 16-bit q | k | v the two-launch form stores
+        rc = lib.oake_debug_ln_gemm16(x.data_ptr(), wq.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bq.data_ptr(),
+                                      qkv16.data_ptr(), nn_ * L, 3 * c_, c_, DT[dtype], 0, s)
+        if rc: bad += 1; print('RC', rc, 'ln_gemm16 (reference of ln_qkv_attn)', (nn_, L, heads)); continue
+        torch.cuda.synchronize()
+        q, kk, v = qkv16.float().view(nn_, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        ref = (torch.softmax(q @ kk.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(nn_ * L, c_)
+        check('ln_qkv_attn', out, ref, 1.5 * tol, (nn_, L, heads, info[3]))
     elif kind == 4:  # attention + the object token (oadp/oake/objects.py:232-247)
         nn_, heads = int(rng.integers(1, 40)), int(rng.integers(1, 13))
         L = int(rng.integers(193, 209)) if rng.random() < 0.5 else int(rng.integers(65, 225))
