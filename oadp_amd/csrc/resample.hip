@@ -86,6 +86,13 @@ __device__ __forceinline__ uint8_t clip8(int v) {
   return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// One filter tap: pixel (0 .. 255) x fixed-point coefficient.  Pillow's 8-bit coefficients are round(w * 2^22) with |w| <= 1
+// (normalize_coeffs_8bpc, PRECISION_BITS = 22), so both factors fit 24 signed bits and the product is v_mul_i32_i24 /
+// v_mad_i32_i24 — full-rate instructions — where a 32-bit `*` compiles to v_mul_lo_u32 / v_mad_u64_u32 at a quarter of the
+// rate (68 + 44 of them per thread of the horizontal pass: the pass was multiply-bound at 0.12 of the HBM peak).  Same
+// integers: the low 32 bits of the exact product.
+__device__ __forceinline__ int tap(int px, int k) { return __mul24(px, k); }
+
 // 16 bytes from a 4-byte-aligned address (global_load_dwordx4 needs no more)
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -126,17 +133,17 @@ __device__ __forceinline__ void resample_h_pixel(const ResampleJob& jb, const ui
       const unsigned w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sh), w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sh),
                      w2 = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
       const int k0 = k[t], k1 = k[t + 1], k2 = k[t + 2], k3 = k[t + 3];
-      s0 += (int)(w0 & 0xffu) * k0; s1 += (int)((w0 >> 8) & 0xffu) * k0; s2 += (int)((w0 >> 16) & 0xffu) * k0;
-      s0 += (int)(w0 >> 24) * k1; s1 += (int)(w1 & 0xffu) * k1; s2 += (int)((w1 >> 8) & 0xffu) * k1;
-      s0 += (int)((w1 >> 16) & 0xffu) * k2; s1 += (int)(w1 >> 24) * k2; s2 += (int)(w2 & 0xffu) * k2;
-      s0 += (int)((w2 >> 8) & 0xffu) * k3; s1 += (int)((w2 >> 16) & 0xffu) * k3; s2 += (int)(w2 >> 24) * k3;
+      s0 += tap((int)(w0 & 0xffu), k0); s1 += tap((int)((w0 >> 8) & 0xffu), k0); s2 += tap((int)((w0 >> 16) & 0xffu), k0);
+      s0 += tap((int)(w0 >> 24), k1); s1 += tap((int)(w1 & 0xffu), k1); s2 += tap((int)((w1 >> 8) & 0xffu), k1);
+      s0 += tap((int)((w1 >> 16) & 0xffu), k2); s1 += tap((int)(w1 >> 24), k2); s2 += tap((int)(w2 & 0xffu), k2);
+      s0 += tap((int)((w2 >> 8) & 0xffu), k3); s1 += tap((int)((w2 >> 16) & 0xffu), k3); s2 += tap((int)(w2 >> 24), k3);
     }
     for (; t < cnt; ++t) {
       const uint8_t* p = q + 3 * t;
       const int kv = k[t];
-      s0 += p[0] * kv;
-      s1 += p[1] * kv;
-      s2 += p[2] * kv;
+      s0 += tap(p[0], kv);
+      s1 += tap(p[1], kv);
+      s2 += tap(p[2], kv);
     }
   } else if (row_ok) {
     const uint8_t* rowp = img + sy * sy_step;
@@ -145,9 +152,9 @@ __device__ __forceinline__ void resample_h_pixel(const ResampleJob& jb, const ui
       if (sx >= 0 && sx < sx_lim) {
         const uint8_t* p = rowp + sx * sx_step;
         const int kv = k[t];
-        s0 += p[0] * kv;
-        s1 += p[1] * kv;
-        s2 += p[2] * kv;
+        s0 += tap(p[0], kv);
+        s1 += tap(p[1], kv);
+        s2 += tap(p[2], kv);
       }
     }
   }
@@ -210,10 +217,10 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const ResampleJob* __re
         const u32x4_a4 d = *reinterpret_cast<const u32x4_a4*>(a & ~(uintptr_t)3);
         const unsigned w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sh), w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sh),
                        w2 = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
-        acc[r][0] += (int)(w0 & 0xffu) * k0; acc[r][1] += (int)((w0 >> 8) & 0xffu) * k0; acc[r][2] += (int)((w0 >> 16) & 0xffu) * k0;
-        acc[r][0] += (int)(w0 >> 24) * k1; acc[r][1] += (int)(w1 & 0xffu) * k1; acc[r][2] += (int)((w1 >> 8) & 0xffu) * k1;
-        acc[r][0] += (int)((w1 >> 16) & 0xffu) * k2; acc[r][1] += (int)(w1 >> 24) * k2; acc[r][2] += (int)(w2 & 0xffu) * k2;
-        acc[r][0] += (int)((w2 >> 8) & 0xffu) * k3; acc[r][1] += (int)((w2 >> 16) & 0xffu) * k3; acc[r][2] += (int)(w2 >> 24) * k3;
+        acc[r][0] += tap((int)(w0 & 0xffu), k0); acc[r][1] += tap((int)((w0 >> 8) & 0xffu), k0); acc[r][2] += tap((int)((w0 >> 16) & 0xffu), k0);
+        acc[r][0] += tap((int)(w0 >> 24), k1); acc[r][1] += tap((int)(w1 & 0xffu), k1); acc[r][2] += tap((int)((w1 >> 8) & 0xffu), k1);
+        acc[r][0] += tap((int)((w1 >> 16) & 0xffu), k2); acc[r][1] += tap((int)(w1 >> 24), k2); acc[r][2] += tap((int)(w2 & 0xffu), k2);
+        acc[r][0] += tap((int)((w2 >> 8) & 0xffu), k3); acc[r][1] += tap((int)((w2 >> 16) & 0xffu), k3); acc[r][2] += tap((int)(w2 >> 24), k3);
       }
     }
     for (; t < cnt; ++t) {
@@ -221,9 +228,9 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const ResampleJob* __re
 #pragma unroll
       for (int r = 0; r < kHRows; ++r) {
         const uint8_t* p = q + r * sy_step + 3 * t;
-        acc[r][0] += p[0] * kv;
-        acc[r][1] += p[1] * kv;
-        acc[r][2] += p[2] * kv;
+        acc[r][0] += tap(p[0], kv);
+        acc[r][1] += tap(p[1], kv);
+        acc[r][2] += tap(p[2], kv);
       }
     }
 #pragma unroll
@@ -265,9 +272,9 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const ResampleJob* __re
       for (int t = 0; t < cnt; ++t) {
         const uint8_t* q = tcol + (long)(ymin + t) * jb.rw * 3;
         const int kv = k[t];
-        s0 += q[0] * kv;
-        s1 += q[1] * kv;
-        s2 += q[2] * kv;
+        s0 += tap(q[0], kv);
+        s1 += tap(q[1], kv);
+        s2 += tap(q[2], kv);
       }
       v0 = clip8(s0); v1 = clip8(s1); v2 = clip8(s2);
     }
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void resample_v4_kernel(const ResampleJob* __r
         load12(tcol + (long)(ymin + tt) * rstep, w);
         const int kv = k[tt];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) acc[i] += (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu) * kv;
+        for (int i = 0; i < 12; ++i) acc[i] += tap((int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu), kv);
       }
 #pragma unroll
       for (int i = 0; i < 12; ++i) acc[i] = clip8(acc[i]);
@@ -359,9 +366,9 @@ __global__ __launch_bounds__(256) void resample_v4_kernel(const ResampleJob* __r
           for (int tt = 0; tt < cnt; ++tt) {
             const uint8_t* q = tcol + (long)(ymin + tt) * jb.rw * 3;
             const int kv = k[tt];
-            s0 += q[0] * kv;
-            s1 += q[1] * kv;
-            s2 += q[2] * kv;
+            s0 += tap(q[0], kv);
+            s1 += tap(q[1], kv);
+            s2 += tap(q[2], kv);
           }
           v0 = clip8(s0); v1 = clip8(s1); v2 = clip8(s2);
         }
@@ -412,9 +419,9 @@ __global__ __launch_bounds__(256) void resample_v_u8_kernel(const ResampleJob* _
   for (int t = 0; t < cnt; ++t) {
     const uint8_t* q = tcol + (long)(ymin + t) * jb.rw * 3;
     const int kv = k[t];
-    s0 += q[0] * kv;
-    s1 += q[1] * kv;
-    s2 += q[2] * kv;
+    s0 += tap(q[0], kv);
+    s1 += tap(q[1], kv);
+    s2 += tap(q[2], kv);
   }
   o[0] = clip8(s0);
   o[1] = clip8(s1);
