@@ -474,13 +474,11 @@ __global__ __launch_bounds__(768) void qkv_attn_kernel(const T* __restrict__ A, 
 
 // rows of the folded in-projection, head-major: out row h * 192 + 64 m + j  <-  in row m * C + 64 h + j   (m = q, k, v)
 __global__ void permute_qkv_rows_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int C, int chunks_per_row) {
-  const int H = C / kHeadDim;
   const long total = (long)3 * C * chunks_per_row;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ro = (int)(i / chunks_per_row), ch = (int)(i - (long)ro * chunks_per_row);
     const int h = ro / 192, rem = ro - h * 192, m = rem >> 6, j = rem & 63;
     const int ri = m * C + h * kHeadDim + j;
-    (void)H;
     out[i] = in[(long)ri * chunks_per_row + ch];
   }
 }
