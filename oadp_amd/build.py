@@ -18,7 +18,7 @@ ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
-SOURCES = ['gemm.hip', 'attention.hip', 'qkv_attn.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'qkv_attn.hip', 'qkv_attn_obj.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
 LAB_ONLY_SOURCES = ['attn_out.hip']  # kernels that lost their A/B: liboake_hip_lab.so only
 HEADERS = ['common.h', 'kernels.h', 'attention_head.inc', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'
@@ -26,7 +26,9 @@ ARCH = 'gfx950'
 # attn_out itself up to SPILL_SMALL bytes — its out_proj waves sit at the 168-register limit and hipcc parks a few
 # epilogue values (one accumulator tile, lane offsets) in scratch: stored once, reloaded once per image, outside the loops
 SPILL_OK = ('attn_out_kernelIDF16_Lb1E',)
-SPILL_SMALL = {'attn_out_kernel': 128}
+# qkv_attn_obj_kernel: the DMA waves' tile-end attention task and row group 1's two-tile task park up to 24 registers
+# once per TILE, outside the K loop — checked in the ISA (hipcc -S: no scratch_ instruction inside a Depth=2 loop body)
+SPILL_SMALL = {'attn_out_kernel': 128, 'qkv_attn_obj_kernel': 128}
 FLAGS = [
     f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
     '-Wall', '-Wno-unused-function',

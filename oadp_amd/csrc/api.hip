@@ -855,7 +855,10 @@ int ensure_qkv_perm(oake_handle* h) {
     if (!w.in_wfp) HIP_TRY(h, hipMalloc(&w.in_wfp, 3 * C * C * 2));
     if (!w.in_csp) HIP_TRY(h, hipMalloc((void**)&w.in_csp, 3 * C * 4));
     if (!w.in_bfp) HIP_TRY(h, hipMalloc((void**)&w.in_bfp, 3 * C * 4));
-    HIP_TRY(h, launch_permute_qkv(h->dt16, w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
+    if (qkv_attn_obj_supported(h->tokens, h->cfg.heads, h->cfg.width, 1))  // (a handle has ONE geometry)
+      HIP_TRY(h, launch_permute_qkv_obj(w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
+    else
+      HIP_TRY(h, launch_permute_qkv(h->dt16, w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
   }
   HIP_TRY(h, hipStreamSynchronize(0));
   h->qkv_perm = true;
@@ -890,6 +893,12 @@ int main_block_tail(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
       launch_attention(h->dt16, h->qkv, h->att, nb, L, h->cfg.heads, h->text ? 1 : 0, s, nullptr, nullptr, 0,
                        nullptr, &h->opts));
   return mlp_rows(h, s, w, 0, T, "");
+}
+
+// objects mode: ln_1 + in_proj + attention of both streams (a crop's tokens and its object token) as ONE kernel
+bool fuses_qkv_attn_obj(const oake_handle* h, int nb) {
+  return h->fuse_qkv_attn && h->stat_fused && !h->text && h->xdt != DT_F32 && h->qkv_perm &&
+         qkv_attn_obj_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
 }
 
 // ln_1 + in_proj + attention of the main token stream as one kernel, then out_proj + MLP
@@ -936,7 +945,8 @@ int check_ready(oake_handle* h) {
   }
   h->folded = true;
   if (h->fuse_qkv_attn && !h->text && h->xdt != DT_F32 && !h->qkv_perm &&
-      qkv_attn_supported(h->tokens, h->cfg.heads, h->cfg.width, 1))
+      (qkv_attn_supported(h->tokens, h->cfg.heads, h->cfg.width, 1) ||
+       qkv_attn_obj_supported(h->tokens, h->cfg.heads, h->cfg.width, 1)))
     return ensure_qkv_perm(h);
   return OAKE_OK;
 }
@@ -1254,6 +1264,17 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
     for (int l = 0; l < c.layers; ++l) {
       const LayerW& w = h->layers[l];
       const bool last = (l == c.layers - 1);
+      if (!last && fuses_qkv_attn_obj(h, nb) && w.in_wfp) {
+        // ... as one kernel per layer: a tile = (crop, head), the crop's object token rides as row L of the tile
+        int np = 0;
+        if ((rc = ln_stats(h, s, reinterpret_cast<const char*>(h->x), 0, T + nb, 3 * C, C, &np))) return rc;
+        if (np < 1) return fail(h, OAKE_ERR_STATE, "qkv_attn_obj: no row statistics");
+        RUNK(h, s, "qkv_attn", 2.0 * (T + nb) * 3 * C * C + 4.0 * nb * c.heads * ((double)L * L + L) * 64, 0.0,
+             launch_qkv_attn_obj(h->dt16, h->x, w.in_wfp, w.in_bfp, w.in_csp, h->rowpart, np, masks, mask_dtype, h->att,
+                                 nb, L, c.heads, &h->opts, s));
+        if ((rc = mlp_rows(h, s, w, 0, T + nb, ""))) return rc;
+        continue;
+      }
       if (!last) {
         // ln_1 + in-proj of both streams; k/v of the patch rows serve both (Appendix C #1)
         if ((rc = in_proj_rows(h, s, w, 0, T + nb, false, "gemm_qkv"))) return rc;
@@ -1776,6 +1797,34 @@ int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_g
   for (int i = 0; i < (repeats < 1 ? 1 : repeats) && e == hipSuccess; ++i)
     e = launch_qkv_attn(dtype16, d_x, wp, bfp, csp, part, 1, d_out, n_img, l, heads, &t_debug_opts, s,
                         reinterpret_cast<unsigned long long*>(d_trace));
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(wf); (void)hipFree(wp); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(csp); (void)hipFree(bfp);
+  (void)hipFree(part);
+  return dbg(e);
+}
+
+int oake_debug_ln_qkv_attn_obj(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
+                               const float* d_bias, const void* d_mask, int mask_dtype, void* d_out, int n_img, int l,
+                               int heads, int dtype16, void* d_trace, int repeats, void* stream) {
+  const int C = heads * 64, n = 3 * C, m = n_img * l + n_img;
+  if (!d_x || !d_w32 || !d_gamma || !d_beta || !d_bias || !d_mask || !d_out || n_img < 1) return OAKE_ERR_INVALID;
+  if (!qkv_attn_obj_supported(l, heads, C, n_img)) return OAKE_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  void *wf = nullptr, *wp = nullptr;
+  float *cs = nullptr, *bf = nullptr, *csp = nullptr, *bfp = nullptr, *part = nullptr;
+  hipError_t e = hipMalloc(&wf, (size_t)n * C * 2);
+  if (e == hipSuccess) e = hipMalloc(&wp, (size_t)n * C * 2);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&cs), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bf), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&csp), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bfp), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&part), (size_t)m * 32 * 4);
+  if (e == hipSuccess) e = launch_fold_ln(dtype16, d_w32, d_gamma, d_beta, d_bias, wf, cs, bf, n, C, s);
+  if (e == hipSuccess) e = launch_rowsums(d_x, dtype16, C, part, m, C, s);
+  if (e == hipSuccess) e = launch_permute_qkv_obj(wf, bf, cs, wp, bfp, csp, C, s);
+  for (int i = 0; i < (repeats < 1 ? 1 : repeats) && e == hipSuccess; ++i)
+    e = launch_qkv_attn_obj(dtype16, d_x, wp, bfp, csp, part, 1, d_mask, mask_dtype, d_out, n_img, l, heads, &t_debug_opts, s,
+                            reinterpret_cast<unsigned long long*>(d_trace));
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(wf); (void)hipFree(wp); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(csp); (void)hipFree(bfp);
   (void)hipFree(part);

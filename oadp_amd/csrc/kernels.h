@@ -176,6 +176,17 @@ hipError_t launch_qkv_attn(int dtype16, const void* x, const void* wp, const flo
                            const float* rowpart, int nparts, void* out, int n_img, int L, int heads,
                            const LaunchOpts* opts, hipStream_t s, unsigned long long* trace = nullptr);
 
+// ... and objects mode (qkv_attn_obj.hip): 192 < L + 1 <= 200 rows per crop = its L tokens + its object token (row T + crop
+// of x / rowpart / out, T = n_img * L); mask [n_img, L - 1] (1 = background) of mask_dtype DT_F16 | DT_F32.  out rows
+// 0 .. T - 1 = the patch stream's attention, rows T .. T + n - 1 the object tokens' [REF oadp/oake/objects.py:223-247].
+// wp / biasp / colsump in the kernel's own column order (launch_permute_qkv_obj).
+bool qkv_attn_obj_supported(int L, int heads, int width, int n_img);
+hipError_t launch_permute_qkv_obj(const void* w, const float* bias, const float* colsum, void* wp, float* biasp,
+                                  float* colsump, int width, hipStream_t s);
+hipError_t launch_qkv_attn_obj(int dtype16, const void* x, const void* wp, const float* biasp, const float* colsump,
+                               const float* rowpart, int nparts, const void* mask, int mask_dtype, void* out, int n_img,
+                               int L, int heads, const LaunchOpts* opts, hipStream_t s, unsigned long long* trace = nullptr);
+
 // ---- head tail ---------------------------------------------------------------------------
 // rows of [n, e] fp32 -> optional L2 normalise (F.normalize, eps 1e-12) -> out [n, e] (fp32 or f16)
 hipError_t launch_l2norm_rows(const float* in, void* out, int out_dtype, int normalize, int n, int e,

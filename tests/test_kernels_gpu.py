@@ -220,8 +220,73 @@ def test_ln_qkv_attention_fused(lib, cuda, dtype, n, l, heads):
     assert torch.equal(out[n * l:], torch.full((3, c), 7.0, dtype=dtype, device=cuda))  # nothing written past the rows
 
 
+def _objects_attention_ref(qkv, n, l, heads, mask):
+    """The two attentions of objects mode from q | k | v rows [n*l + n, 3C] (token rows, then one object-token row per
+    crop): tokens over their crop's tokens; the object token over its crop's PATCH rows (-100 * mask) and itself
+    [REF oadp/oake/objects.py:223-247]."""
+    c = heads * 64
+    x, y = qkv[:n * l].float(), qkv[n * l:].float()
+    q, k, v = x.view(n, l, 3, heads, 64).permute(2, 0, 3, 1, 4)                 # [n, h, l, 64]
+    out_x = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(n * l, c)
+    qy, ky, vy = y.view(n, 1, 3, heads, 64).permute(2, 0, 3, 1, 4)              # [n, h, 1, 64]
+    keys, vals = torch.cat([k[:, :, 1:], ky], 2), torch.cat([v[:, :, 1:], vy], 2)
+    bias = torch.cat([-100.0 * mask.float(), torch.zeros(n, 1, device=mask.device)], 1)[:, None, None, :]
+    out_y = (torch.softmax(qy @ keys.transpose(-1, -2) + bias, dim=-1) @ vals).permute(0, 2, 1, 3).reshape(n, c)
+    return torch.cat([out_x, out_y])
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('mask_dtype', [torch.float16, torch.float32])
+@pytest.mark.parametrize('n,l,heads', [(1, 197, 12), (3, 197, 12), (128, 197, 12), (5, 197, 3), (2, 192, 4), (40, 199, 5),
+                                       (30, 193, 12), (300, 197, 12)])
+def test_ln_qkv_attention_objects_fused(lib, cuda, dtype, mask_dtype, n, l, heads):
+    """csrc/qkv_attn_obj.hip: objects mode's ln_1 + in_proj + BOTH attentions (a crop's tokens; its object token with the
+    mask bias) as ONE persistent kernel, a tile = (crop, head) of 208 rows, against fp32 torch on the 16-bit q | k | v the
+    two-launch form stores (oake_debug_ln_gemm16).  128 crops = 1536 tiles = six per block; 300 crops: ragged rounds;
+    l = 192 / 193 / 199: the ends of the range the form takes (13 key tiles, two regions of l + 1 rows in one ring
+    slot); masks: random, one crop all foreground, one all
+    background."""
+    if n * l * heads * 64 > 30_000_000:
+        heads = 12
+    c = heads * 64
+    m = n * l + n
+    g = torch.Generator(device='cpu').manual_seed(n * 1000 + l * 10 + heads)
+    x = torch.randn(m, c, generator=g) * 1.5 + 0.3
+    x[:, 7] *= 12.0
+    x = x.to(dtype).to(cuda)
+    w = torch.randn(3 * c, c, generator=g) * (c ** -0.5)
+    w[:c] *= 0.35
+    w = w.to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(c, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(c, generator=g)).to(cuda)
+    bias = (0.5 * torch.randn(3 * c, generator=g)).to(cuda)
+    mask = (torch.rand(n, l - 1, generator=g) < 0.4).float()
+    mask[0] = 0
+    if n > 1:
+        mask[1] = 1
+    md = mask.to(mask_dtype).to(cuda)
+    out = torch.full((m + 3, c), 7.0, dtype=dtype, device=cuda)
+    rc = lib.oake_debug_ln_qkv_attn_obj(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+                                        md.data_ptr(), _lib.OAKE_F16 if mask_dtype == torch.float16 else _lib.OAKE_F32,
+                                        out.data_ptr(), n, l, heads, DT[dtype], None, 1, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    qkv16 = torch.empty(m, 3 * c, dtype=dtype, device=cuda)
+    assert lib.oake_debug_ln_gemm16(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+                                    qkv16.data_ptr(), m, 3 * c, c, DT[dtype], 0, _stream()) == 0
+    torch.cuda.synchronize()
+    ref = _objects_attention_ref(qkv16, n, l, heads, mask.to(cuda))
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    torch.testing.assert_close(out[:n * l].float(), ref[:n * l], rtol=tol, atol=tol)   # the token stream
+    torch.testing.assert_close(out[n * l:m].float(), ref[n * l:], rtol=tol, atol=tol)  # the object tokens
+    assert torch.equal(out[m:], torch.full((3, c), 7.0, dtype=dtype, device=cuda))
+
+
 def test_ln_qkv_attention_refuses_long_sequences(lib, cuda):
     z = torch.zeros(64, device=cuda)
+    for bad_l in (191, 200, 207, 50):  # objects form: 192 <= l <= 199 only
+        assert lib.oake_debug_ln_qkv_attn_obj(*([z.data_ptr()] * 6), _lib.OAKE_F16, z.data_ptr(), 1, bad_l, 12,
+                                              _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
     args = [z.data_ptr()] * 6
     assert lib.oake_debug_ln_qkv_attn(*args, 1, 54, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
     assert lib.oake_debug_ln_qkv_attn(*args, 1, 197, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
