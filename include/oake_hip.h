@@ -323,11 +323,17 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               out_proj weights stream through each CU's 64 B/clk vector-memory path once per
  *                               image): the kernel is in the lab build liboake_hip_lab.so only; the
  *                               production library answers OAKE_ERR_INVALID to a non-zero value.  Default 0.
- *   OAKE_OPT_FUSE_QKV_ATTN      sequences of at most 53 tokens on a 16-bit residual stream (encode_image at 224^2 / patch
- *                               32, blocks mode): ln_1 + attn.in_proj + softmax(q k^T) v of a layer run as ONE persistent
- *                               kernel — a tile is (three images, one head), the q | k | v values go from the MFMA
- *                               accumulators through LDS into the attention and never reach memory (csrc/qkv_attn.hip).
- *                               Same 16-bit q / k / v values as the two-launch form.  [REF oadp/oake/globals.py:57]
+ *   OAKE_OPT_FUSE_QKV_ATTN      on a 16-bit residual stream, ln_1 + attn.in_proj + softmax(q k^T) v of a layer run as
+ *                               ONE persistent kernel: the q | k | v values go from the MFMA accumulators through LDS
+ *                               into the attention and never reach memory.  Same 16-bit q / k / v values as the
+ *                               two-launch form.  0: off.  1 (default): sequences of at most 50 tokens (encode_image at
+ *                               224^2 / patch 32, blocks mode) as tiles of (four images, one head) of 208 rows, 51 .. 53
+ *                               tokens as tiles of (three images, one head) of 160 rows; objects mode (192 .. 199 tokens
+ *                               per crop + its object token, oake_encode_objects) as tiles of (crop, head) with the
+ *                               object token's masked attention in the same kernel (csrc/qkv_attn_obj.hip,
+ *                               csrc/qkv_attn.hip).  2: as 1, the three-image form for every sequence of at most 53
+ *                               tokens (measurement).  Other values: OAKE_ERR_INVALID.
+ *                               [REF oadp/oake/globals.py:57, oadp/oake/objects.py:223-247]
  *   OAKE_OPT_PASS_CROPS         crops per internal encoder pass (vision handles).  get: the cap in force — what
  *                               oake_create derived from cfg.max_batch and the ~25 600-token-row target
  *                               (OAKE_PASS_ROWS).  set: a bound >= 1; the cap becomes min(value, the cap the handle

@@ -42,11 +42,16 @@ OAKE_API int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const flo
 OAKE_API int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
                            const float* d_bias, void* d_out, int n_img, int l, int heads, int dtype16, void* d_trace,
                            int repeats, void* stream);
+/* The same contract as oake_debug_ln_qkv_attn through the 208-row tile kernel's QUAD form (csrc/qkv_attn_obj.hip: four images
+ * of l <= 50 tokens per tile).  d_trace (or NULL): 64 x 3 x 6 x 8 uint64 cycle stamps. */
+OAKE_API int oake_debug_ln_qkv_attn_quad(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
+                                         const float* d_bias, void* d_out, int n_img, int l, int heads, int dtype16,
+                                         void* d_trace, int repeats, void* stream);
 /* Objects mode (csrc/qkv_attn_obj.hip): x 16-bit [n_img*l + n_img, heads*64] = the crops' token rows, then one object-token
  * row per crop; mask [n_img, l-1] (OAKE_F16 | OAKE_F32, 1 = background).  out16 rows 0 .. n_img*l-1 = self-attention of the
  * token rows over their crop's tokens, rows n_img*l .. = the object tokens over their crop's patch rows (-100 * mask) and
  * themselves — with (q | k | v) = LayerNorm(x) W^T + bias rounded to 16 bits, as ONE kernel.  192 < l + 1 <= 200 else
- * OAKE_ERR_UNSUPPORTED.  Synchronous.  d_trace (or NULL): 64 x 2 x 6 x 8 uint64 cycle stamps of the first blocks' tile phases. */
+ * OAKE_ERR_UNSUPPORTED.  Synchronous.  d_trace (or NULL): 64 x 3 x 6 x 8 uint64 cycle stamps of the first blocks' tile phases. */
 OAKE_API int oake_debug_ln_qkv_attn_obj(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
                                const float* d_bias, const void* d_mask, int mask_dtype, void* d_out, int n_img, int l,
                                int heads, int dtype16, void* d_trace, int repeats, void* stream);

@@ -82,6 +82,7 @@ DEBUG_SIGNATURES = {
     'oake_debug_attention': (_I, [_VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_ln_qkv_attn_obj': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _VP]),
     'oake_debug_ln_qkv_attn': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),
+    'oake_debug_ln_qkv_attn_quad': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),
     'oake_debug_attention_objects': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_attn_out': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_attn_out_trace': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP]),

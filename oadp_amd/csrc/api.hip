@@ -847,6 +847,16 @@ int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, c
   return gemm(h, s, n_pr.c_str(), resid, hb, w.proj_w, w.proj_b, xr, M, C, F, C, nullptr, nullptr, r0);
 }
 
+// which fused form a handle's geometry takes: the 208-row tile kernel (csrc/qkv_attn_obj.hip: objects mode, or four images
+// of <= 50 tokens per tile) or the 160-row one (csrc/qkv_attn.hip: three images of <= 53 tokens; fuse_qkv_attn == 2 asks
+// for it where both apply) — they read the folded in-projection in different column orders
+bool uses_qkv_attn_quad(const oake_handle* h) {
+  return h->fuse_qkv_attn == 1 && qkv_attn_quad_supported(h->tokens, h->cfg.heads, h->cfg.width, 1);
+}
+bool qkv_perm_is_obj(const oake_handle* h) {
+  return qkv_attn_obj_supported(h->tokens, h->cfg.heads, h->cfg.width, 1) || uses_qkv_attn_quad(h);
+}
+
 // the head-major copies of the folded in-projection (qkv_attn.hip): made on the first pass that takes the fused path
 int ensure_qkv_perm(oake_handle* h) {
   if (h->qkv_perm) return OAKE_OK;
@@ -855,7 +865,7 @@ int ensure_qkv_perm(oake_handle* h) {
     if (!w.in_wfp) HIP_TRY(h, hipMalloc(&w.in_wfp, 3 * C * C * 2));
     if (!w.in_csp) HIP_TRY(h, hipMalloc((void**)&w.in_csp, 3 * C * 4));
     if (!w.in_bfp) HIP_TRY(h, hipMalloc((void**)&w.in_bfp, 3 * C * 4));
-    if (qkv_attn_obj_supported(h->tokens, h->cfg.heads, h->cfg.width, 1))  // (a handle has ONE geometry)
+    if (qkv_perm_is_obj(h))  // (a handle has ONE geometry)
       HIP_TRY(h, launch_permute_qkv_obj(w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
     else
       HIP_TRY(h, launch_permute_qkv(h->dt16, w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
@@ -867,8 +877,9 @@ int ensure_qkv_perm(oake_handle* h) {
 
 // true when the main token stream of this pass takes ln_1 + in_proj + attention as ONE kernel (qkv_attn.hip)
 bool fuses_qkv_attn(const oake_handle* h, int nb) {
-  return h->fuse_qkv_attn && h->stat_fused && !h->text && h->xdt != DT_F32 &&
-         qkv_attn_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
+  if (!(h->fuse_qkv_attn && h->stat_fused && !h->text && h->xdt != DT_F32)) return false;
+  if (uses_qkv_attn_quad(h)) return qkv_attn_quad_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
+  return !qkv_perm_is_obj(h) && qkv_attn_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
 }
 
 int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_only) {
@@ -907,6 +918,12 @@ int main_qkv_attn(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
   int np = 0, rc;
   if ((rc = ln_stats(h, s, reinterpret_cast<const char*>(h->x), 0, T, 3 * C, C, &np))) return rc;
   if (np < 1 || !w.in_wfp) return fail(h, OAKE_ERR_STATE, "qkv_attn: no row statistics / permuted weights");
+  if (uses_qkv_attn_quad(h) && qkv_attn_quad_supported(L, h->cfg.heads, C, nb)) {
+    RUNK(h, s, "qkv_attn", 2.0 * T * 3 * C * C + 4.0 * nb * h->cfg.heads * (double)L * L * 64, 0.0,
+         launch_qkv_attn_quad(h->dt16, h->x, w.in_wfp, w.in_bfp, w.in_csp, h->rowpart, np, h->att, nb, L, h->cfg.heads,
+                              &h->opts, s, nullptr));
+    return mlp_rows(h, s, w, 0, T, "");
+  }
   RUNK(h, s, "qkv_attn", 2.0 * T * 3 * C * C + 4.0 * nb * h->cfg.heads * (double)L * L * 64, 0.0,
        launch_qkv_attn(h->dt16, h->x, w.in_wfp, w.in_bfp, w.in_csp, h->rowpart, np, h->att, nb, L, h->cfg.heads,
                        &h->opts, s));
@@ -945,8 +962,7 @@ int check_ready(oake_handle* h) {
   }
   h->folded = true;
   if (h->fuse_qkv_attn && !h->text && h->xdt != DT_F32 && !h->qkv_perm &&
-      (qkv_attn_supported(h->tokens, h->cfg.heads, h->cfg.width, 1) ||
-       qkv_attn_obj_supported(h->tokens, h->cfg.heads, h->cfg.width, 1)))
+      (qkv_attn_supported(h->tokens, h->cfg.heads, h->cfg.width, 1) || qkv_perm_is_obj(h)))
     return ensure_qkv_perm(h);
   return OAKE_OK;
 }
@@ -1803,6 +1819,34 @@ int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_g
   return dbg(e);
 }
 
+int oake_debug_ln_qkv_attn_quad(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
+                                const float* d_bias, void* d_out, int n_img, int l, int heads, int dtype16, void* d_trace,
+                                int repeats, void* stream) {
+  const int C = heads * 64, n = 3 * C, m = n_img * l;
+  if (!d_x || !d_w32 || !d_gamma || !d_beta || !d_bias || !d_out || n_img < 1) return OAKE_ERR_INVALID;
+  if (!qkv_attn_quad_supported(l, heads, C, n_img)) return OAKE_ERR_UNSUPPORTED;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  void *wf = nullptr, *wp = nullptr;
+  float *cs = nullptr, *bf = nullptr, *csp = nullptr, *bfp = nullptr, *part = nullptr;
+  hipError_t e = hipMalloc(&wf, (size_t)n * C * 2);
+  if (e == hipSuccess) e = hipMalloc(&wp, (size_t)n * C * 2);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&cs), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bf), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&csp), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bfp), (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&part), (size_t)m * 32 * 4);
+  if (e == hipSuccess) e = launch_fold_ln(dtype16, d_w32, d_gamma, d_beta, d_bias, wf, cs, bf, n, C, s);
+  if (e == hipSuccess) e = launch_rowsums(d_x, dtype16, C, part, m, C, s);
+  if (e == hipSuccess) e = launch_permute_qkv_obj(wf, bf, cs, wp, bfp, csp, C, s);
+  for (int i = 0; i < (repeats < 1 ? 1 : repeats) && e == hipSuccess; ++i)
+    e = launch_qkv_attn_quad(dtype16, d_x, wp, bfp, csp, part, 1, d_out, n_img, l, heads, &t_debug_opts, s,
+                             reinterpret_cast<unsigned long long*>(d_trace));
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(wf); (void)hipFree(wp); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(csp); (void)hipFree(bfp);
+  (void)hipFree(part);
+  return dbg(e);
+}
+
 int oake_debug_ln_qkv_attn_obj(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
                                const float* d_bias, const void* d_mask, int mask_dtype, void* d_out, int n_img, int l,
                                int heads, int dtype16, void* d_trace, int repeats, void* stream) {
@@ -1976,7 +2020,13 @@ int oake_set_option(oake_handle* h, int option, int value) {
                              "liboake_hip_lab.so only (measured slower: DESIGN.md 9.R4 item 4)");
       return OAKE_OK;
 #endif
-    case OAKE_OPT_FUSE_QKV_ATTN: h->fuse_qkv_attn = value ? 1 : 0; return OAKE_OK;
+    case OAKE_OPT_FUSE_QKV_ATTN: {
+      if (value < 0 || value > 2) return fail(h, OAKE_ERR_INVALID, "OAKE_OPT_FUSE_QKV_ATTN: 0, 1 or 2");
+      const bool was_obj = qkv_perm_is_obj(h);
+      h->fuse_qkv_attn = value;
+      if (qkv_perm_is_obj(h) != was_obj) h->qkv_perm = false;  // (the other form's column order: permuted again on the next pass)
+      return OAKE_OK;
+    }
     case OAKE_OPT_PASS_CROPS:
       if (h->text) return fail(h, OAKE_ERR_INVALID, "pass_crops: vision handles only");
       if (value < 1) return fail(h, OAKE_ERR_INVALID, "pass_crops must be >= 1");

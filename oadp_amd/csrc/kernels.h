@@ -181,6 +181,12 @@ hipError_t launch_qkv_attn(int dtype16, const void* x, const void* wp, const flo
 // 0 .. T - 1 = the patch stream's attention, rows T .. T + n - 1 the object tokens' [REF oadp/oake/objects.py:223-247].
 // wp / biasp / colsump in the kernel's own column order (launch_permute_qkv_obj).
 bool qkv_attn_obj_supported(int L, int heads, int width, int n_img);
+// ... and its QUAD form for short sequences: FOUR images of L <= 50 tokens per 208-row tile (plain self-attention per image;
+// batch 256 x 12 heads = 768 tiles = exactly three rounds of 256 CUs, where three images per 160-row tile make 1032 = 4.03)
+bool qkv_attn_quad_supported(int L, int heads, int width, int n_img);
+hipError_t launch_qkv_attn_quad(int dtype16, const void* x, const void* wp, const float* biasp, const float* colsump,
+                                const float* rowpart, int nparts, void* out, int n_img, int L, int heads,
+                                const LaunchOpts* opts, hipStream_t s, unsigned long long* trace);
 hipError_t launch_permute_qkv_obj(const void* w, const float* bias, const float* colsum, void* wp, float* biasp,
                                   float* colsump, int width, hipStream_t s);
 hipError_t launch_qkv_attn_obj(int dtype16, const void* x, const void* wp, const float* biasp, const float* colsump,

@@ -230,6 +230,133 @@ __device__ __forceinline__ void obj_task_pv(const ObjTask<T> (&st)[NQ], const ch
   }
 }
 
+// ---- QUAD mode: four images of L <= 50 tokens per tile (rows 0 .. 4 L - 1), plain self-attention per image ----
+// 16 tasks: task tk = (image tk >> 2 of the tile, query tile tk & 3) against the image's <= 64 keys (4 key tiles, the
+// padded keys masked).  Wave w takes task w, the DMA waves (idle through the q | k and v writes) also task w + 4: four
+// tasks on every SIMD.
+template <typename T>
+struct QuadTask {
+  typename T16<T>::vec8 pf[2];
+  float inv;
+};
+
+// NT tasks tk, tk + 4, .. in ONE instruction stream (a task this small is one wave's dependent chain LDS read -> MFMA ->
+// row maximum -> exp -> row sum: two of them interleaved take little longer than one)
+template <typename T, int NT>
+__device__ __forceinline__ void quad_task_s(QuadTask<T> (&st)[NT], const char* qs, const char* ks, int tk, int L, int tid_) {
+  typedef typename T16<T>::vec8 vec8;
+  int atid = tid_;
+  asm volatile("" : "+v"(atid));
+  const int fr = atid & 15, g = (atid & 63) >> 4;
+  vec8 qf[NT][2];
+  f32x4 sacc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r0 = ((tk + 4 * t) >> 2) * L;  // the image's first row of the tile
+    const int row = r0 + 16 * (tk & 3) + fr;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *reinterpret_cast<const vec8*>(qs + row * kRowBytes + (((kk * 4 + g) ^ sw) << 4));
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int r0 = ((tk + 4 * t) >> 2) * L;
+      const int ksw = ((r0 + fr) >> 1) & 7;  // (+ 16 kt: the same swizzle)
+      const vec8 kf0 = *reinterpret_cast<const vec8*>(ks + (r0 + kt * 16 + fr) * kRowBytes + ((g ^ ksw) << 4));
+      const vec8 kf1 = *reinterpret_cast<const vec8*>(ks + (r0 + kt * 16 + fr) * kRowBytes + (((4 + g) ^ ksw) << 4));
+      sacc[t][kt] = T16<T>::mfma(kf0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+      sacc[t][kt] = T16<T>::mfma(kf1, qf[t][1], sacc[t][kt]);
+    }
+  float mx[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    mx[t] = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if ((kt + 1) * 16 > L) {  // (wave-uniform) a key tile with keys past the image: rows of the next image, or none
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[t][kt][r] = kt * 16 + 4 * g + r < L ? sacc[t][kt][r] : -1e30f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx[t] = fmaxf(mx[t], sacc[t][kt][r]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mx[t] = rows16_max(mx[t]);
+  float sum[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float nb = -mx[t] * kLog2e;
+    sum[t] = 0.f;
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      vec8 p8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[t][2 * ks2 + (j >> 2)][j & 3], kLog2e, nb));
+        sum[t] += e;
+        p8[j] = to16<T>(e);
+      }
+      st[t].pf[ks2] = p8;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) st[t].inv = __builtin_amdgcn_rcpf(rows16_sum(sum[t]));
+}
+
+// out_tile: the tile's first output row at the head's columns; rows_left: rows of the matrix from the tile's first on
+template <typename T, int NT>
+__device__ __forceinline__ void quad_task_pv(const QuadTask<T> (&st)[NT], const char* vs, int tk, int L, char* out_tile,
+                                             int rows_left, int C, int tid_) {
+  typedef typename T16<T>::vec8 vec8;
+  typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+  int atid = tid_;
+  asm volatile("" : "+v"(atid));
+  const int fr = atid & 15, g = (atid & 63) >> 4;
+  f32x4 oacc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int c4 = (fr & 3) * 4;
+#pragma unroll
+  for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int row0 = ((tk + 4 * t) >> 2) * L + 4 * g + (fr >> 2);  // + 32 ks (+ 16): the same swizzle
+        const int vsw = (row0 >> 1) & 7;
+        const char* p0 = vs + (row0 + 32 * ks2) * kRowBytes + (((dt * 2 + (c4 >> 3)) ^ vsw) << 4) + (c4 & 4) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 16 * kRowBytes));
+        s16x8 both;
+        both[0] = lo[0]; both[1] = lo[1]; both[2] = lo[2]; both[3] = lo[3];
+        both[4] = hi[0]; both[5] = hi[1]; both[6] = hi[2]; both[7] = hi[3];
+        oacc[t][dt] = T16<T>::mfma(__builtin_bit_cast(vec8, both), st[t].pf[ks2], oacc[t][dt]);
+      }
+  const int q = 16 * (tk & 3) + fr;
+  const unsigned ooff = (unsigned)(16 * (g >> 1) + 32 * (g & 1));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r0 = ((tk + 4 * t) >> 2) * L;
+    const bool live = q < L && r0 + q < rows_left;
+    char* dst = out_tile + (size_t)(r0 + q) * (size_t)(2 * C);
+    const float inv = st[t].inv;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const f32x4 oa = oacc[t][2 * half], ob = oacc[t][2 * half + 1];
+      const uint2 xa = pack4<T>(oa[0] * inv, oa[1] * inv, oa[2] * inv, oa[3] * inv);
+      const uint2 xb = pack4<T>(ob[0] * inv, ob[1] * inv, ob[2] * inv, ob[3] * inv);
+      const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(xa.x, xb.x, false, false);
+      const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(xa.y, xb.y, false, false);
+      if (live) store16_policy<1>(dst + ooff + 64u * half, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
+    }
+  }
+}
+
 #define QO_PIN() __builtin_amdgcn_sched_barrier(0)
 #define QO_BAR()                  \
   do {                            \
@@ -246,7 +373,7 @@ __device__ __forceinline__ void obj_task_pv(const ObjTask<T> (&st)[NQ], const ch
 
 // one compute wave: row group ROW0 .. ROW0 + 16 MI - 1 (group 0: MI = 7; group 1, one phase behind: MI = 6), columns
 // 48 wn .. + 47 = (q, k, v) x 16 head-dim columns 16 wn ..
-template <typename T, int MI, int ROW0, bool LATE>
+template <typename T, bool QUAD, int MI, int ROW0, bool LATE>
 __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, const QkvAttnObjParams& p, T* out, int C,
                                                  int nk, int my_tiles, int xb, int xslot, int per_xcd) {
   typedef typename T16<T>::vec8 vec8;
@@ -254,7 +381,8 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
   const int lane = tid & 63;
   const int wn = wid & 3;
   const int L = p.L, H = p.H;
-  const int region = (L + 1) * kRowBytes;
+  const int region = (QUAD ? 4 * L : L + 1) * kRowBytes;
+  const int rows_live = QUAD ? 4 * L : L + 1;  // tile rows that hold tokens
   const int frow = lane & 15, fg = lane >> 4;
   const int fsw = (frow >> 1) & 7;
   const int a_base = (ROW0 + frow) * kRowBytes;
@@ -337,7 +465,7 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
           acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (ni == 2) {
             vpk[mi] = pk;
-          } else if (R <= L) {
+          } else if (R < rows_live) {
             *reinterpret_cast<uint2*>(qs + ni * region + R * kRowBytes + ((cch ^ ((R >> 1) & 7)) << 4) + coff) = pk;
           }
         }
@@ -347,8 +475,11 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
     QO_BAR();  // X2: q and k of the crop's head are in LDS
     if (stamp) QO_STAMP(LATE ? 1 : 0, ti, 3);
     constexpr int NQ = LATE ? 2 : 1;  // (row group 1 is compiled for two tiles; only wave 4 takes the 13th)
-    ObjTask<T> task[NQ];
-    if (LATE && wid == 4) {
+    ObjTask<T> task[QUAD ? 1 : NQ];
+    QuadTask<T> qtask[1];
+    if constexpr (QUAD) {
+      quad_task_s<T, 1>(qtask, qs, ks, wid, L, tid);
+    } else if (LATE && wid == 4) {
       obj_task_s<T, NQ>(task, qs, ks, smem + kLMbias, wid * 16, L, tid);
     } else {
       obj_task_s<T, 1>(reinterpret_cast<ObjTask<T>(&)[1]>(task[0]), qs, ks, smem + kLMbias, wid * 16, L, tid);
@@ -364,7 +495,7 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int R = ROW0 + mi * 16 + er;
-        if (R <= L) *reinterpret_cast<uint2*>(qs + R * kRowBytes + (((d0 >> 3) ^ ((R >> 1) & 7)) << 4) + ((d0 & 7) << 1)) = vpk[mi];
+        if (R < rows_live) *reinterpret_cast<uint2*>(qs + R * kRowBytes + (((d0 >> 3) ^ ((R >> 1) & 7)) << 4) + ((d0 & 7) << 1)) = vpk[mi];
       }
     }
     QO_BAR();  // X4: v is in LDS (over the q region)
@@ -372,12 +503,18 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
     {
       const int tile = xb + xslot + ti * per_xcd;
       const int img = tile / H, head = tile - img * H;
-      char* orow = reinterpret_cast<char*>(out + (size_t)img * L * C + head * kHeadDim);
-      char* oy = reinterpret_cast<char*>(out + (size_t)(p.T + img) * C + head * kHeadDim);
-      if (LATE && wid == 4) {
-        obj_task_pv<T, NQ>(task, qs, wid * 16, L, orow, oy, C, tid);
+      if constexpr (QUAD) {
+        const int row_first = img * 4 * L;  // (img: the tile's group of four images)
+        quad_task_pv<T, 1>(qtask, qs, wid, L, reinterpret_cast<char*>(out + (size_t)row_first * C + head * kHeadDim),
+                        p.T - row_first, C, tid);
       } else {
-        obj_task_pv<T, 1>(reinterpret_cast<const ObjTask<T>(&)[1]>(task[0]), qs, wid * 16, L, orow, oy, C, tid);
+        char* orow = reinterpret_cast<char*>(out + (size_t)img * L * C + head * kHeadDim);
+        char* oy = reinterpret_cast<char*>(out + (size_t)(p.T + img) * C + head * kHeadDim);
+        if (LATE && wid == 4) {
+          obj_task_pv<T, NQ>(task, qs, wid * 16, L, orow, oy, C, tid);
+        } else {
+          obj_task_pv<T, 1>(reinterpret_cast<const ObjTask<T>(&)[1]>(task[0]), qs, wid * 16, L, orow, oy, C, tid);
+        }
       }
     }
     QO_BAR();  // X5: the slot goes back to the ring
@@ -386,7 +523,7 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
   }
 }
 
-template <typename T>
+template <typename T, bool QUAD>
 __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                            T* __restrict__ out, int K, QkvAttnObjParams p) {
   constexpr int NW = 8, NL = 4;
@@ -400,7 +537,7 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
   const int L = p.L, H = p.H;
   const int C = H * kHeadDim;
   const int nx = 8;
-  const int ntiles = p.n_img * H;
+  const int ntiles = (QUAD ? (p.n_img + 3) / 4 : p.n_img) * H;
   const int xcd = blockIdx.x % nx, xslot = blockIdx.x / nx;
   const int per_xcd = gridDim.x / nx;
   const int q_ = ntiles / nx, r_ = ntiles % nx;
@@ -415,12 +552,16 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
     // ================= DMA wave =================
     const int lw = wid - NW;
     const int npl = lw < 2 ? 13 : 12;
-    const int region = (L + 1) * kRowBytes;
+    const int region = (QUAD ? 4 * L : L + 1) * kRowBytes;
     // per-lane byte offsets of the wave's pieces from the (wave-uniform) A / W base: 13 registers, not 13 address pairs
     unsigned src[NPLMAX];
     const char* const a_bytes = reinterpret_cast<const char*>(A);
     const char* const w_bytes = reinterpret_cast<const char*>(W);
     auto row_of = [&](int img, int rr) {  // global row of tile row rr: the crop's tokens, then its object token (and padding)
+      if (QUAD) {  // (img: the group of four images; rows past the matrix: any row, their results are not stored)
+        const int m = img * 4 * L + rr;
+        return m < p.T ? m : p.T - 1;
+      }
       return rr < L ? img * L + rr : p.T + img;
     };
     auto set_src = [&](int tile_i) {
@@ -516,7 +657,7 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
         typedef __attribute__((address_space(3))) f32x2* lds_f2w_t;
         *(lds_f2w_t)(smem + kLRowstat + (lw * RPW + lane) * 8) = f32x2{st_rstd, st_shift};
       }
-      if (d_kt == 1 && lw == 2) {
+      if (!QUAD && d_kt == 1 && lw == 2) {
         int img, head;
         tile_of(d_tile, img, head);
         // the object token's key rules as one additive row: -60000 = not a key (the CLS row), -100 * mask on the
@@ -564,7 +705,12 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
         const int dti = d_tile - 1;
         if (dstamp) QO_STAMP(2, dti, 0);
         ObjTask<T> task[1];
-        obj_task_s<T, 1>(task, qs, ks, smem + kLMbias, (NW + lw) * 16, L, tid);
+        QuadTask<T> qtask[2];
+        if constexpr (QUAD) {
+          quad_task_s<T, 2>(qtask, qs, ks, NW + lw, L, tid);  // (tasks 8 + lw and 12 + lw)
+        } else {
+          obj_task_s<T, 1>(task, qs, ks, smem + kLMbias, (NW + lw) * 16, L, tid);
+        }
         if (dstamp) QO_STAMP(2, dti, 1);
         QO_BAR();  // X3
         if (dstamp) QO_STAMP(2, dti, 2);
@@ -572,9 +718,15 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
         if (dstamp) QO_STAMP(2, dti, 3);
         int img, head;
         tile_of(d_tile - 1, img, head);
-        char* orow = reinterpret_cast<char*>(out + (size_t)img * L * C + head * kHeadDim);
-        char* oy = reinterpret_cast<char*>(out + (size_t)(p.T + img) * C + head * kHeadDim);
-        obj_task_pv<T, 1>(task, qs, (NW + lw) * 16, L, orow, oy, C, tid);
+        if constexpr (QUAD) {
+          const int row_first = img * 4 * L;
+          char* ot = reinterpret_cast<char*>(out + (size_t)row_first * C + head * kHeadDim);
+          quad_task_pv<T, 2>(qtask, qs, NW + lw, L, ot, p.T - row_first, C, tid);
+        } else {
+          char* orow = reinterpret_cast<char*>(out + (size_t)img * L * C + head * kHeadDim);
+          char* oy = reinterpret_cast<char*>(out + (size_t)(p.T + img) * C + head * kHeadDim);
+          obj_task_pv<T, 1>(task, qs, (NW + lw) * 16, L, orow, oy, C, tid);
+        }
         if (dstamp) QO_STAMP(2, dti, 4);
         QO_BAR();  // X5
       }
@@ -587,9 +739,9 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
   }
   // ================= compute waves =================
   if (wid < 4)
-    obj_compute_wave<T, 7, 0, false>(smem, tid, wid, p, out, C, nk, my_tiles, xb, xslot, per_xcd);
+    obj_compute_wave<T, QUAD, 7, 0, false>(smem, tid, wid, p, out, C, nk, my_tiles, xb, xslot, per_xcd);
   else
-    obj_compute_wave<T, 6, 112, true>(smem, tid, wid, p, out, C, nk, my_tiles, xb, xslot, per_xcd);
+    obj_compute_wave<T, QUAD, 6, 112, true>(smem, tid, wid, p, out, C, nk, my_tiles, xb, xslot, per_xcd);
 }
 
 // rows of the folded in-projection in the kernel's column order: out row h * 192 + 48 wn + 16 m + j  <-  in row
@@ -618,6 +770,12 @@ bool qkv_attn_obj_supported(int L, int heads, int width, int n_img) {
          width / BK >= 3 && n_img >= 1;
 }
 
+bool qkv_attn_quad_supported(int L, int heads, int width, int n_img) {
+  // (four images per tile: 4 L rows of q and of k in ONE ring slot, <= 64 keys per image)
+  return L >= 1 && 2 * 4 * L * kRowBytes <= kLStage && heads >= 1 && width == heads * kHeadDim && width % BK == 0 && width / BK >= 3 &&
+         n_img >= 1;
+}
+
 hipError_t launch_permute_qkv_obj(const void* w, const float* bias, const float* colsum, void* wp, float* biasp,
                                   float* colsump, int width, hipStream_t s) {
   const int chunks = width * 2 / 16;
@@ -629,13 +787,13 @@ hipError_t launch_permute_qkv_obj(const void* w, const float* bias, const float*
   return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, bool QUAD>
 static hipError_t qkv_attn_obj_launch_t(const void* x, const void* wp, const float* biasp, const float* colsump,
                                         const float* rowpart, int nparts, const void* mask, int mask_dtype, void* out,
                                         int n_img, int L, int heads, const LaunchOpts* opts, hipStream_t s,
                                         unsigned long long* trace) {
   static DynLdsAttr attr;
-  auto kern = qkv_attn_obj_kernel<T>;
+  auto kern = qkv_attn_obj_kernel<T, QUAD>;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), kLLdsBytes); e != hipSuccess) return e;
   int num_cu = 0;
   if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
@@ -647,7 +805,7 @@ static hipError_t qkv_attn_obj_launch_t(const void* x, const void* wp, const flo
   p.n_img = n_img; p.L = L; p.H = heads; p.T = n_img * L;
   p.mask = mask; p.mask_f16 = mask_dtype == DT_F16 ? 1 : 0;
   p.trace = trace;
-  const int ntiles = n_img * heads;
+  const int ntiles = (QUAD ? (n_img + 3) / 4 : n_img) * heads;
   int grid = (num_cu / 8) * 8;
   if (grid < 8) grid = 8;
   const int need = ((ntiles + 7) / 8) * 8;
@@ -664,8 +822,17 @@ hipError_t launch_qkv_attn_obj(int dtype16, const void* x, const void* wp, const
       (mask_dtype != DT_F16 && mask_dtype != DT_F32))
     return hipErrorInvalidValue;
   if (dtype16 == DT_BF16)
-    return qkv_attn_obj_launch_t<bf16_t>(x, wp, biasp, colsump, rowpart, nparts, mask, mask_dtype, out, n_img, L, heads, opts, s, trace);
-  return qkv_attn_obj_launch_t<f16_t>(x, wp, biasp, colsump, rowpart, nparts, mask, mask_dtype, out, n_img, L, heads, opts, s, trace);
+    return qkv_attn_obj_launch_t<bf16_t, false>(x, wp, biasp, colsump, rowpart, nparts, mask, mask_dtype, out, n_img, L, heads, opts, s, trace);
+  return qkv_attn_obj_launch_t<f16_t, false>(x, wp, biasp, colsump, rowpart, nparts, mask, mask_dtype, out, n_img, L, heads, opts, s, trace);
+}
+
+hipError_t launch_qkv_attn_quad(int dtype16, const void* x, const void* wp, const float* biasp, const float* colsump,
+                                const float* rowpart, int nparts, void* out, int n_img, int L, int heads,
+                                const LaunchOpts* opts, hipStream_t s, unsigned long long* trace) {
+  if (!qkv_attn_quad_supported(L, heads, heads * kHeadDim, n_img) || nparts < 1) return hipErrorInvalidValue;
+  if (dtype16 == DT_BF16)
+    return qkv_attn_obj_launch_t<bf16_t, true>(x, wp, biasp, colsump, rowpart, nparts, nullptr, DT_F32, out, n_img, L, heads, opts, s, trace);
+  return qkv_attn_obj_launch_t<f16_t, true>(x, wp, biasp, colsump, rowpart, nparts, nullptr, DT_F32, out, n_img, L, heads, opts, s, trace);
 }
 
 }  // namespace oake

@@ -328,7 +328,9 @@ def test_encode_image_fused_qkv_attention(cuda, dtype, tol):
     """ln_1 + in_proj + attention as one kernel per layer (csrc/qkv_attn.hip, OAKE_OPT_FUSE_QKV_ATTN) on the full
     ViT-B/32: against the oracle, against the two-launch form (the same 16-bit q / k / v values: the features agree to
     the rounding of different summation orders), that it really is the path taken (profile slot names), and that an
-    image's result does not depend on its position in its three-image tile or in the batch."""
+    image's result does not depend on its position in its tile or in the batch.  Value 1 takes the four-images-per-tile
+    form at L = 50 (csrc/qkv_attn_obj.hip's QUAD form), value 2 the three-image one: switching re-permutes the folded
+    in-projection (the forms read it in different column orders)."""
     sd = synthetic_state_dict()
     model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48)
     x = synthetic_images(46, seed=146)  # 46 = 15 groups of three + one: a ragged last tile
@@ -353,9 +355,20 @@ def test_encode_image_fused_qkv_attention(cuda, dtype, tol):
     assert 'qkv_attn' not in names and names.get('attention') == 11 and names.get('gemm_qkv') == 11, names
     _check(plain, ref, tol, tol)
     assert (fused - plain).abs().max().item() <= tol
+    v.set_option('fuse_qkv_attn', 2)
+    v.profile(True)
+    triple = model.encode_image(xg, normalize=True, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    names = {p['name']: p['launches'] for p in v.profile_read() if p['launches'] > 0}
+    v.profile(False)
+    assert names.get('qkv_attn') == 11 and 'attention' not in names and 'gemm_qkv' not in names, names
+    _check(triple, ref, tol, tol)
+    assert (fused - triple).abs().max().item() <= tol
     v.set_option('fuse_qkv_attn', 1)
     again = model.encode_image(xg.flip(0), normalize=True, out_dtype=torch.float32).flip(0)
     assert (again - fused).abs().max().item() <= 3e-4  # (the last layer's small GEMMs pick tiles by row position)
+    with pytest.raises(Exception):
+        v.set_option('fuse_qkv_attn', 3)
 
 
 def test_pass_limit_is_a_memory_bound(cuda):

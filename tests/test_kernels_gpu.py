@@ -180,14 +180,21 @@ def _attention_ref(qkv, n, l, heads):
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('form', ['triple', 'quad'])
 @pytest.mark.parametrize('n,l,heads', [(3, 50, 12), (1, 50, 12), (2, 50, 12), (256, 50, 12), (7, 50, 3), (100, 50, 12),
-                                       (5, 53, 4), (4, 17, 3), (3, 1, 3), (9, 33, 12), (770, 50, 12)])
-def test_ln_qkv_attention_fused(lib, cuda, dtype, n, l, heads):
+                                       (5, 53, 4), (4, 17, 3), (3, 1, 3), (9, 33, 12), (770, 50, 12), (5, 49, 4),
+                                       (1030, 50, 12), (6, 48, 3)])
+def test_ln_qkv_attention_fused(lib, cuda, dtype, n, l, heads, form):
     """csrc/qkv_attn.hip: ln_1 folded into attn.in_proj + softmax(q k^T) v as ONE persistent kernel (a tile = three
     images x one head; q | k | v go from the accumulators through LDS into the attention) against the same chain in
     fp32 torch from the same 16-bit x: LayerNorm -> in_proj -> ROUNDED to 16 bits (as the two-launch form stores it) ->
     attention.  Shapes: full groups, a ragged last group (1 and 2 images), several tiles per block with different
-    heads (256 x 12 = 1032 tiles; 770 images = 3084 tiles: 12 per block), other sequence lengths and head counts."""
+    heads (256 x 12 = 1032 tiles; 770 images = 3084 tiles: 12 per block), other sequence lengths and head counts.
+    form 'quad': the same contract through csrc/qkv_attn_obj.hip's four-images-per-208-row-tile form (l <= 50; odd l: the
+    images' rows start at odd LDS rows; 1030 images: a last group of two)."""
+    if form == 'quad' and l > 50:
+        pytest.skip('four images of more than 50 tokens do not fit the 208-row tile')
+    entry = lib.oake_debug_ln_qkv_attn_quad if form == 'quad' else lib.oake_debug_ln_qkv_attn
     c = heads * 64
     g = torch.Generator(device='cpu').manual_seed(n * 1000 + l * 10 + heads)
     x = torch.randn(n * l, c, generator=g) * 1.5 + 0.3
@@ -200,8 +207,8 @@ def test_ln_qkv_attention_fused(lib, cuda, dtype, n, l, heads):
     beta = (0.2 * torch.randn(c, generator=g)).to(cuda)
     bias = (0.5 * torch.randn(3 * c, generator=g)).to(cuda)
     out = torch.full((n * l + 3, c), 7.0, dtype=dtype, device=cuda)  # guard rows behind the last image
-    rc = lib.oake_debug_ln_qkv_attn(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
-                                    out.data_ptr(), n, l, heads, DT[dtype], None, 1, _stream())
+    rc = entry(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+               out.data_ptr(), n, l, heads, DT[dtype], None, 1, _stream())
     assert rc == 0
     torch.cuda.synchronize()
     # (a) the attention of the 16-bit q | k | v the two-launch form stores (oake_debug_ln_gemm16: same folded weights,

@@ -4,7 +4,8 @@ to 30 000 (ragged tiles, one row, several tiles per persistent block), N a multi
 incl. the per-slice row sums; attention with 1..6 items, 1..300 keys, 1..12 heads; attention with the objects-mode
 object token fused in (65..224 keys, half of the cases in attention_head_kernel's 193..208; random masks, one crop all
 foreground), both kernel forms the product carries; the fused ln_1 + in_proj + attention kernel (1..400 images, L <= 53,
-3..12 heads) against the two-launch form's 16-bit q | k | v.  usage: kernel_fuzz.py [n=200] [seed=0]"""
+3..12 heads) against the two-launch form's 16-bit q | k | v; the objects-mode form of it (csrc/qkv_attn_obj.hip: 1..150 crops,
+L 192..199, the object token's row per crop, random masks).  usage: kernel_fuzz.py [n=200] [seed=0]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -39,7 +40,7 @@ for it in range(n_cases):
     bias = torch.randn(n, generator=g).to(dev)
     info = (m, n, k, str(dtype).split('.')[-1])
     tol = 3e-3 if dtype == torch.float16 else 2.5e-2
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 7))
     if kind == 0:    # bias / QuickGELU epilogues
         gelu = int(rng.integers(0, 2))
         c = torch.full((m, n), float('nan'), dtype=dtype, device=dev)
@@ -92,9 +93,11 @@ for it in range(n_cases):
         beta = (0.2 * torch.randn(c_, generator=g)).to(dev)
         bq = (0.5 * torch.randn(3 * c_, generator=g)).to(dev)
         out = torch.zeros(nn_ * L, c_, dtype=dtype, device=dev)
-        rc = lib.oake_debug_ln_qkv_attn(x.data_ptr(), wq.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bq.data_ptr(),
-                                        out.data_ptr(), nn_, L, heads, DT[dtype], None, 1, s)
-        if rc: bad += 1; print('RC', rc, 'ln_qkv_attn', (nn_, L, heads)); continue
+        quad = L <= 50 and rng.random() < 0.5  # (the four-images-per-tile form of csrc/qkv_attn_obj.hip)
+        rc = (lib.oake_debug_ln_qkv_attn_quad if quad else lib.oake_debug_ln_qkv_attn)(
+            x.data_ptr(), wq.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bq.data_ptr(), out.data_ptr(), nn_, L, heads,
+            DT[dtype], None, 1, s)
+        if rc: bad += 1; print('RC', rc, 'ln_qkv_attn', (nn_, L, heads, quad)); continue
         qkv16 = torch.empty(nn_ * L, 3 * c_, dtype=dtype, device=dev)  # the 16-bit q | k | v the two-launch form stores
         rc = lib.oake_debug_ln_gemm16(x.data_ptr(), wq.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bq.data_ptr(),
                                       qkv16.data_ptr(), nn_ * L, 3 * c_, c_, DT[dtype], 0, s)
@@ -102,7 +105,43 @@ for it in range(n_cases):
         torch.cuda.synchronize()
         q, kk, v = qkv16.float().view(nn_, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
         ref = (torch.softmax(q @ kk.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(nn_ * L, c_)
-        check('ln_qkv_attn', out, ref, 1.5 * tol, (nn_, L, heads, info[3]))
+        check('ln_qkv_attn' + ('.quad' if quad else ''), out, ref, 1.5 * tol, (nn_, L, heads, info[3]))
+    elif kind == 6:  # objects mode: ln_1 + in_proj + attention + the object token as one kernel (csrc/qkv_attn_obj.hip)
+        nn_, L, heads = int(rng.integers(1, 151)), int(rng.integers(192, 200)), int(rng.integers(3, 13))
+        c_ = heads * 64
+        if nn_ * L * c_ > 20_000_000:
+            nn_ = max(1, 20_000_000 // (L * c_))
+        mdt = torch.float16 if rng.random() < 0.5 else torch.float32
+        T = nn_ * L
+        x = torch.randn(T + nn_, c_, generator=g) * 1.5 + 0.3
+        x[:, int(rng.integers(0, c_))] *= 10.0
+        x = x.to(dtype).to(dev)
+        wq = torch.randn(3 * c_, c_, generator=g) * c_ ** -0.5
+        wq[:c_] *= 0.35
+        wq = wq.to(dev)
+        gamma = (1.0 + 0.3 * torch.randn(c_, generator=g)).to(dev)
+        beta = (0.2 * torch.randn(c_, generator=g)).to(dev)
+        bq = (0.5 * torch.randn(3 * c_, generator=g)).to(dev)
+        mask = (torch.rand(nn_, L - 1, generator=g) < rng.random()).float(); mask[0] = 0
+        md = mask.to(mdt).to(dev)
+        out = torch.zeros(T + nn_, c_, dtype=dtype, device=dev)
+        rc = lib.oake_debug_ln_qkv_attn_obj(x.data_ptr(), wq.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bq.data_ptr(),
+                                            md.data_ptr(), _lib.OAKE_F16 if mdt == torch.float16 else _lib.OAKE_F32,
+                                            out.data_ptr(), nn_, L, heads, DT[dtype], None, 1, s)
+        if rc: bad += 1; print('RC', rc, 'ln_qkv_attn_obj', (nn_, L, heads)); continue
+        qkv16 = torch.empty(T + nn_, 3 * c_, dtype=dtype, device=dev)
+        rc = lib.oake_debug_ln_gemm16(x.data_ptr(), wq.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bq.data_ptr(),
+                                      qkv16.data_ptr(), T + nn_, 3 * c_, c_, DT[dtype], 0, s)
+        if rc: bad += 1; print('RC', rc, 'ln_gemm16 (reference of ln_qkv_attn_obj)', (nn_, L, heads)); continue
+        torch.cuda.synchronize()
+        q, kk, v = qkv16[:T].float().view(nn_, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        ref = (torch.softmax(q @ kk.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(T, c_)
+        check('ln_qkv_attn_obj.x', out[:T], ref, 1.5 * tol, (nn_, L, heads, info[3]))
+        qq, ky, vy = qkv16[T:].float().view(nn_, 1, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        keys, vals = torch.cat([kk[:, :, 1:], ky], 2), torch.cat([v[:, :, 1:], vy], 2)
+        bias_ = torch.cat([-100.0 * mask.to(dev), torch.zeros(nn_, 1, device=dev)], 1)[:, None, None, :]
+        refy = (torch.softmax(qq @ keys.transpose(-1, -2) + bias_, dim=-1) @ vals).permute(0, 2, 1, 3).reshape(nn_, c_)
+        check('ln_qkv_attn_obj.y', out[T:], refy, 1.5 * tol, (nn_, L, heads, info[3]))
     elif kind == 4:  # attention + the object token (oadp/oake/objects.py:232-247)
         nn_, heads = int(rng.integers(1, 40)), int(rng.integers(1, 13))
         L = int(rng.integers(193, 209)) if rng.random() < 0.5 else int(rng.integers(65, 225))

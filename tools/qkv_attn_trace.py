@@ -1,6 +1,7 @@
 """Where does a workgroup of qkv_attn_kernel (csrc/qkv_attn.hip) spend its cycles?  Cycle stamps of the first blocks'
 tile phases (wave 0 = row group 0, wave 4 = row group 1, wave 8 = DMA wave 0) + the launch time.  GPU box only.
-usage: python tools/qkv_attn_trace.py [n_img=256] [L=50]      (L >= 192: the objects-mode kernel, csrc/qkv_attn_obj.hip)"""
+usage: python tools/qkv_attn_trace.py [n_img=256] [L=50] [quad]     (L >= 192: the objects-mode kernel, csrc/qkv_attn_obj.hip;
+'quad': its four-images-per-tile form at L <= 50)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,6 +20,7 @@ gamma, beta, bias = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch
 out = torch.empty(n * l, c, dtype=torch.float16, device=dev)
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 OBJ = l >= 192
+QUAD = len(sys.argv) > 3 and sys.argv[3] == 'quad'  # (l <= 50 through the 208-row tile kernel's four-image form)
 if OBJ:
     x = (torch.randn(n * l + n, c, generator=g) * 1.5).half().to(dev)
     out = torch.empty(n * l + n, c, dtype=torch.float16, device=dev)
@@ -29,14 +31,14 @@ def run(reps, trace=None):
                                             mask.data_ptr(), 1, out.data_ptr(), n, l, heads, 1, trace, reps, s)
         assert rc == 0, rc
         return
-    rc = lib.oake_debug_ln_qkv_attn(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
-                                    out.data_ptr(), n, l, heads, 1, trace, reps, s)
+    rc = (lib.oake_debug_ln_qkv_attn_quad if QUAD else lib.oake_debug_ln_qkv_attn)(
+        x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(), out.data_ptr(), n, l, heads, 1, trace, reps, s)
     assert rc == 0, rc
 run(3)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record(); run(20); e1.record(); torch.cuda.synchronize()
 print(f'n {n} L {l}: {e0.elapsed_time(e1) * 50:.1f} us per launch incl. the debug entry\'s fold / permute passes / 20', flush=True)
-if OBJ:
+if OBJ or QUAD:
     trace = torch.zeros(64 * 3 * 6 * 8, dtype=torch.int64, device=dev)
     run(1, C.c_void_p(trace.data_ptr()))
     t = trace.view(64, 3, 6, 8).cpu()
