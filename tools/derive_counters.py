@@ -25,7 +25,7 @@ PEAK_FLOPS, PEAK_HBM, SIMDS, XCDS = 2.5e15, 8e12, 1024, 8
 SLOTS = {'im2col_kernel': 'im2col', 'pad_nchw_kernel': 'pad_nchw', 'embed_ln_pre_kernel': 'embed_ln_pre',
          'gemm_pp_kernelIDF16_Li6E': 'gemm_conv1', 'gemm_pp_kernelIDF16_Li7E': 'gemm_qkv', 'gemm_pp_kernelIDF16_Li8E': 'gemm_c_fc',
          'gemm_pp_kernelIDF16_Li5E': ('gemm_out_proj', 'gemm_c_proj'), 'attention_pair_kernel': 'attention',
-         'attention_coop_kernel': 'attention', 'qkv_attn_kernel': 'qkv_attn',
+         'attention_coop_kernel': 'attention', 'qkv_attn_kernel': 'qkv_attn', 'qkv_attn_obj_kernel': 'qkv_attn',
          # objects mode, 12 layers: 11 launches with the patch stream, then the last layer's object token alone
          'attention_head_kernel': ('attention',) * 11 + ('object_attention',), 'attn_out_kernel': 'attn_out', 'object_attention_kernel': 'object_attention',
          'crop_normalize_jobs_kernel': 'crop_normalize', 'resample_h_kernel': 'resample_h', 'resample_v4_kernel': 'resample_v',
@@ -54,7 +54,12 @@ def dispatches(path, by='Dispatch_Id'):
 
 def per_slot(path):
     seen, acc = collections.Counter(), collections.defaultdict(list)
-    for d in dispatches(path):
+    ds = dispatches(path)
+    # objects mode with the fused ln_1 + in_proj + attention kernel: attention_head_kernel is left with the last layer's
+    # object token alone (one launch per pass)
+    if any('qkv_attn_obj_kernel' in d['name'] for d in ds):
+        SLOTS['attention_head_kernel'] = 'object_attention'
+    for d in ds:
         s = slot_of(d['name'], seen)
         if s:
             acc[s].append(d)
