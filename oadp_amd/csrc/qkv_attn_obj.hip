@@ -1,5 +1,10 @@
-// qkv_attn_obj.hip — objects mode: LayerNorm-folded QKV in-projection + self-attention of ONE crop's 197 tokens AND its
-// object token as one persistent kernel for gfx950 (192 < L + 1 <= 200 rows per crop).
+// qkv_attn_obj.hip — the fused ln_1 + in_proj + attention kernel on a 208-row tile, two forms of one kernel template:
+//   * objects mode (QUAD = false): LayerNorm-folded QKV in-projection + self-attention of ONE crop's 197 tokens AND its
+//     object token as one persistent kernel for gfx950 (192 < L + 1 <= 200 rows per crop) — described first;
+//   * QUAD = true: FOUR images of L <= 50 tokens per tile, plain self-attention per image (encode_image at 224^2 / patch 32,
+//     blocks mode [REF oadp/oake/globals.py:57; oadp/oake/blocks.py:129]): the same K loop and tile-end phases, 16 tasks
+//     (image, query tile) instead of 13 query tiles, no object token.  Batch 256 x 12 heads = 768 tiles = three exact rounds
+//     of 256 CUs (qkv_attn.hip's three-image 160-row tile: 1032 = 4.03).  See "QUAD mode" below.
 //
 //   reference ops  Hooks.residual_attention_block_forward_pre + the block's own attention
 //                  [REF oadp/oake/objects.py:223-247: y attends over ln_1(cat([x[1:], y])) with the -100 * mask bias;
