@@ -499,9 +499,19 @@ __global__ __launch_bounds__(256) void object_attention_kernel(const T* __restri
   __builtin_amdgcn_wave_barrier();
 
   // out[d = lane] = sum_k p[k] V[k][d]
-  float acc = 0.f;
-  for (int k = 0; k < L - 1; ++k)
-    acc += ps[wid][k] * to32<T>(xb[(size_t)(1 + k) * ld + 2 * C + lane]);
+  // (eight V rows in flight per wave, four accumulators in key order k mod 4: the loop is load-latency-bound)
+  float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+  const T* vb = xb + ld + 2 * C + lane;  // V row of patch key 0
+  int k = 0;
+  for (; k + 8 <= L - 1; k += 8) {
+    T v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = vb[(size_t)(k + j) * ld];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc4[j & 3] += ps[wid][k + j] * to32<T>(v[j]);
+  }
+  for (; k < L - 1; ++k) acc4[k & 3] += ps[wid][k] * to32<T>(vb[(size_t)k * ld]);
+  float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
   acc += ps[wid][L - 1] * to32<T>(yb[2 * C + lane]);
   out[(size_t)n * C + h * kHeadDim + lane] = to16<T>(acc * inv);
 }
