@@ -134,6 +134,11 @@ struct TileMap {
 #ifndef OAKE_RESID_NT
 #define OAKE_RESID_NT 0
 #endif
+// the persistent kernel's residual epilogue: x as the accumulators' initial values (1, production) or loaded and added at
+// the tile end (0: the form of rounds 1-4, A/B builds)
+#ifndef OAKE_RESID_INIT
+#define OAKE_RESID_INIT 1
+#endif
 template <typename V>
 __device__ __forceinline__ V resid_load16(const V* p) {
 #if OAKE_RESID_NT
@@ -269,7 +274,9 @@ __device__ __forceinline__ float4 epi_vec4(const float* gptr, int n, const char*
     return *reinterpret_cast<const float4*>(gptr + n);
 }
 
-template <typename T, int EPI, int MI, int NI, bool FULL, bool ELDS>
+// RIA ("residual in accumulators", EPI_RESID16 in the persistent kernel): the tile's x values were the accumulators'
+// INITIAL values (tile_resid_init below), so the epilogue neither loads nor adds them
+template <typename T, int EPI, int MI, int NI, bool FULL, bool ELDS, bool RIA = false>
 __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mbase, int nwave, int g,
                                                    int M, int N, const EpiParams& ep, bool reset,
                                                    const char* elds, int lcol, int lrow) {
@@ -328,7 +335,7 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
                                                                    (size_t)_m * ep.ldo + _n));  \
     }                                                                                           \
   } while (0)
-    if constexpr (EPI == EPI_RESID16) {
+    if constexpr (EPI == EPI_RESID16 && !RIA) {
 #pragma unroll
       for (int mi = 0; mi < (kAhead < MI ? kAhead : MI); ++mi) OAKE_FETCH_RESID(mi);
     }
@@ -361,7 +368,7 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
       for (int t = 0; t < NP; ++t) {
         const int n = nwave + 32 * t + 8 * g;
         const bool ok = FULL || (mok && n < N);
-        if (EPI == EPI_RESID16) {
+        if (EPI == EPI_RESID16 && !RIA) {
           // own piece t: fetched by this lane (A for rows < 8, B for rows >= 8) or by lane r ^ 8
           const vec8 own = xres[EPI == EPI_RESID16 ? mi : 0][t];
           xr[t] = SWAP ? swap_piece(own, xres[EPI == EPI_RESID16 ? mi : 0][NP - 1 - t], t == 0) : own;
@@ -392,7 +399,7 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
             lo[r] = quick_gelu(lo[r]);
             hi[r] = quick_gelu(hi[r]);
           }
-        } else if (EPI == EPI_RESID16) {
+        } else if (EPI == EPI_RESID16 && !RIA) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             lo[r] += to32<T>(xr[t][r]);
@@ -421,7 +428,7 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
         tile_store16(pa, swap_piece(qv[0], qv[1], true));
         tile_store16(pa + (size_t)8 * ep.ldo, swap_piece(qv[1], qv[0], false));
       }
-      if constexpr (EPI == EPI_RESID16) {
+      if constexpr (EPI == EPI_RESID16 && !RIA) {
         if (mi + kAhead < MI) OAKE_FETCH_RESID(mi + kAhead < MI ? mi + kAhead : 0);
       }
       if constexpr (ELDS && EPI == EPI_RESID16) {
@@ -565,14 +572,50 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[MI][NI], int mbase, i
     tile_epilogue_impl<T, EPI, MI, NI, false, false>(acc, mbase, nwave, g, M, N, ep, reset, nullptr, 0, 0);
 }
 
-template <typename T, int EPI, int MI, int NI>
+template <typename T, int EPI, int MI, int NI, bool RIA = false>
 __device__ __forceinline__ void tile_epilogue_lds(f32x4 (&acc)[MI][NI], int mbase, int nwave, int g,
                                                   int M, int N, const EpiParams& ep, bool reset,
                                                   bool interior, const char* elds, int lcol, int lrow) {
   if (interior)
-    tile_epilogue_impl<T, EPI, MI, NI, true, true>(acc, mbase, nwave, g, M, N, ep, reset, elds, lcol, lrow);
+    tile_epilogue_impl<T, EPI, MI, NI, true, true, RIA>(acc, mbase, nwave, g, M, N, ep, reset, elds, lcol, lrow);
   else
-    tile_epilogue_impl<T, EPI, MI, NI, false, true>(acc, mbase, nwave, g, M, N, ep, reset, elds, lcol, lrow);
+    tile_epilogue_impl<T, EPI, MI, NI, false, true, RIA>(acc, mbase, nwave, g, M, N, ep, reset, elds, lcol, lrow);
+}
+
+// EPI_RESID16 in the persistent kernel: x + (A W^T + bias) with the tile's x values as the accumulators' INITIAL values.
+// The ten 16-byte loads per lane are issued where a compute wave has nothing else to do — at kernel entry, while the DMA
+// waves fill the ring (4-6 k cycles), or right behind the previous tile's epilogue — instead of at the tile end, where they
+// were three dependent round trips to the Infinity Cache (x was last touched a GEMM ago) in front of every wave's stores.
+// Paired column mapping as the epilogue's: lane (frow, g) holds x[mbase + 16 mi][nwave + 32 t + 8 g .. + 7] in
+// acc[mi][2 t] (first four) and acc[mi][2 t + 1].  fp32 accumulation starts from x instead of ending with it: the sums
+// differ from the epilogue-add form by fp32 rounding only (both round to 16 bits once, at the store).
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void tile_resid_init(f32x4 (&acc)[MI][NI], int mbase, int nwave, int g, int M, int N,
+                                                const EpiParams& ep, bool interior) {
+  typedef typename T16<T>::vec8 vec8;
+  constexpr int NP = NI / 2;
+  vec8 x[MI][NP];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      const int m = mbase + mi * 16, n = nwave + 32 * t + 8 * g;
+      vec8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = to16<T>(0.f);
+      if (interior || (m < M && n < N))
+        v = resid_load16(reinterpret_cast<const vec8*>(reinterpret_cast<const T*>(ep.out) + (size_t)m * ep.ldo + n));
+      x[mi][t] = v;
+    }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[mi][2 * t][r] = to32<T>(x[mi][t][r]);
+        acc[mi][2 * t + 1][r] = to32<T>(x[mi][t][4 + r]);
+      }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1114,11 +1157,19 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   // (cycle stamps are compiled out of the LN-folded variants: they sit exactly at the VGPR limit)
   unsigned long long* const trace = (EpiTraits<EPI>::kLn || PH2) ? nullptr : tmap.trace;
 
+  // the residual epilogue starts its accumulators from the tile's x values (tile_resid_init)
+  constexpr bool RIA = EPI == EPI_RESID16 && OAKE_RESID_INIT;
   f32x4 acc[MI][NI];
+  if constexpr (RIA) {
+    int m0, n0;
+    tile_origin(tmap, xb + xslot, BM, BN, m0, n0);
+    tile_resid_init<T, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, m0 + BM <= M && n0 + BN <= N);
+  } else {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   vec8 af[MI], bf[NI];
 #define OAKE_LOAD_FRAGS(buf_, koff_)                                                        \
   do {                                                                                      \
@@ -1268,9 +1319,16 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
           }
         }
         if (!deferred)  // edge tile, fp32 output or read-modify-write epilogue: store now
-          tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep,
-                                            false, interior, elds, wn * TN, wm * TM + frow);
-        OAKE_ZERO_ACC();
+          tile_epilogue_lds<T, EPI, MI, NI, RIA>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep,
+                                                 false, interior, elds, wn * TN, wm * TM + frow);
+        if constexpr (RIA) {  // the next tile's x values (this block's own tile: nobody else writes it)
+          int m1, n1;
+          tile_origin(tmap, xb + xslot + c_tile * per_xcd, BM, BN, m1, n1);
+          tile_resid_init<T, MI, NI>(acc, m1 + wm * TM + frow, n1 + wn * TN, fg, M, N, ep,
+                                     m1 + BM <= M && n1 + BN <= N);
+        } else {
+          OAKE_ZERO_ACC();
+        }
         if (trace != nullptr && (tid & 255) == 0 && blockIdx.x < 64 && c_tile <= 8) {
           OAKE_PIN();
           unsigned long long* tr =
@@ -1291,8 +1349,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     int m0, n0;
     tile_origin(tmap, xb + xslot + (my_tiles - 1) * per_xcd, BM, BN, m0, n0);
     const unsigned long long t_ep = trace ? __builtin_readcyclecounter() : 0;
-    tile_epilogue_lds<T, EPI, MI, NI>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, false,
-                                      m0 + BM <= M && n0 + BN <= N, elds, wn * TN, wm * TM + frow);
+    tile_epilogue_lds<T, EPI, MI, NI, RIA>(acc, m0 + wm * TM + frow, n0 + wn * TN, fg, M, N, ep, false,
+                                           m0 + BM <= M && n0 + BN <= N, elds, wn * TN, wm * TM + frow);
     if (trace != nullptr && (tid & 255) == 0 && blockIdx.x < 64 && my_tiles <= 8) {
       unsigned long long* tr =
           trace + (((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 + (my_tiles - 1)) * 4;
