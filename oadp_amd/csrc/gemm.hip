@@ -308,7 +308,8 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
         c1[t] = okc ? epi_vec4<ELDS>(ep.colsum, n + 4, elds, EpiLds::kColsum, lc + 4) : z4;
       }
     }
-    // Residual stream: a row block's 16-B pieces are fetched kAhead row blocks before they are used.
+    // Residual stream, RIA = false (the non-persistent kernels; -DOAKE_RESID_INIT=0): a row block's 16-B pieces are fetched
+    // kAhead row blocks before they are used.
     // x is read and written through the same pointer, so hipcc keeps every load behind the stores
     // that precede it in program order: fetched row by row at the point of use, that was MI
     // dependent round trips to L2 per tile (10k cycles of epilogue); all MI rows up front would not fit
