@@ -229,6 +229,28 @@ __device__ __forceinline__ float quick_gelu(float x) {
   const float e = __builtin_amdgcn_exp2f(x * -2.4554669595930156f);  // 1.702 * log2(e)
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// Four values at once, the full-rate steps as packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two values per instruction; the
+// same operations in the same order as quick_gelu, so the same bits): the c_fc epilogue is bound by the SIMD's issue
+// slots — per value 16 + 16 cycles of v_exp / v_rcp and, unpacked, 5 x 4 of the rest.
+#ifndef OAKE_GELU_PACKED
+#define OAKE_GELU_PACKED 1  // (0: value by value, A/B builds)
+#endif
+__device__ __forceinline__ void quick_gelu4(f32x4& v) {
+#if !OAKE_GELU_PACKED
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+  return;
+#endif
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 k = f32x2{-2.4554669595930156f, -2.4554669595930156f}, one = f32x2{1.0f, 1.0f};
+  f32x2 a = f32x2{v[0], v[1]}, b = f32x2{v[2], v[3]};
+  const f32x2 ta = a * k, tb = b * k;
+  const f32x2 da = f32x2{__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1])} + one;
+  const f32x2 db = f32x2{__builtin_amdgcn_exp2f(tb[0]), __builtin_amdgcn_exp2f(tb[1])} + one;
+  a = a * f32x2{__builtin_amdgcn_rcpf(da[0]), __builtin_amdgcn_rcpf(da[1])};
+  b = b * f32x2{__builtin_amdgcn_rcpf(db[0]), __builtin_amdgcn_rcpf(db[1])};
+  v = f32x4{a[0], a[1], b[0], b[1]};
+}
 
 // XCD-aware bijective block remap (guide T1): hardware places block b on XCD b % 8; give each
 // XCD a contiguous range of logical tiles so neighbouring tiles share that XCD's L2.

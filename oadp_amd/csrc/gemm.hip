@@ -395,11 +395,8 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
           hi[2] = epi_affine<LN>(hi[2], b1[t].z, ch.z, rs); hi[3] = epi_affine<LN>(hi[3], b1[t].w, ch.w, rs);
         }
         if (EpiTraits<EPI>::kGelu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            lo[r] = quick_gelu(lo[r]);
-            hi[r] = quick_gelu(hi[r]);
-          }
+          quick_gelu4(lo);
+          quick_gelu4(hi);
         } else if (EPI == EPI_RESID16 && !RIA) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -533,11 +530,8 @@ __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&p
         hi[2] = epi_affine<LN>(hi[2], b1.z, ch.z, r); hi[3] = epi_affine<LN>(hi[3], b1.w, ch.w, r);
       }
       if (EpiTraits<EPI>::kGelu) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          lo[r4] = quick_gelu(lo[r4]);
-          hi[r4] = quick_gelu(hi[r4]);
-        }
+        quick_gelu4(lo);
+        quick_gelu4(hi);
       }
       const uint2 p0 = pack4<T>(lo[0], lo[1], lo[2], lo[3]);
       const uint2 p1 = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
