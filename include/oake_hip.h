@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define OAKE_ABI_VERSION 3
+#define OAKE_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define OAKE_API __attribute__((visibility("default")))
@@ -93,17 +93,23 @@ typedef struct oake_config {
   int32_t mlp_dim;
   int32_t embed_dim;
   int32_t compute_dtype;
-  int32_t max_batch;      /* workspace is sized for this many crops per internal pass (the vision tower caps it at
-                             ~25 600 token rows per pass: the environment variable OAKE_PASS_ROWS
-                             overrides the target (0 = no cap), OAKE_PASS_CROPS names the cap in crops
-                             directly; a call with more crops is cut into EQUAL passes; csrc/api.hip) */
+  int32_t max_batch;      /* workspace is sized for this many crops per internal pass at most (the vision tower caps
+                             it further by `pass_rows` below; a call with more crops is cut into EQUAL passes;
+                             csrc/api.hip) */
   int32_t residual_dtype; /* element type of the residual stream x: == compute_dtype (default; the
                              reference's GPU model keeps x in fp16 too) or OAKE_F32 */
+  int32_t pass_rows;      /* vision tower: token rows per internal pass the crops-per-pass cap is derived from —
+                             min(max_batch, pass_rows / tokens rounded down to 32, at least 32).  0 = the library's
+                             default, 25 600 rows (a pass's activations then turn over inside the 256-MB Infinity
+                             Cache); < 0 = no row cap (max_batch alone).  The library reads NO environment variable:
+                             the Python host maps OAKE_PASS_ROWS / OAKE_PASS_CROPS onto this field and max_batch
+                             (oadp_amd/clip/model.py); the pass size changes the tile shapes of the small last-layer
+                             GEMMs and therefore the rounding of the results (<= 3e-4 on the unit-norm output) */
 } oake_config;
 
 OAKE_API uint32_t oake_abi_version(void);
 
-/* Fill *cfg with ViT-B/32 defaults (stride 32, padding 0, f16 compute + f16 residual, max_batch 256). */
+/* Fill *cfg with ViT-B/32 defaults (stride 32, padding 0, f16 compute + f16 residual, max_batch 256, pass_rows 0). */
 OAKE_API void oake_default_config(oake_config* cfg);
 
 /* Create a handle on HIP device `device`.  Allocates weights + workspace. */
@@ -335,11 +341,17 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               tokens (measurement).  Other values: OAKE_ERR_INVALID.
  *                               [REF oadp/oake/globals.py:57, oadp/oake/objects.py:223-247]
  *   OAKE_OPT_PASS_CROPS         crops per internal encoder pass (vision handles).  get: the cap in force — what
- *                               oake_create derived from cfg.max_batch and the ~25 600-token-row target
- *                               (OAKE_PASS_ROWS).  set: a bound >= 1; the cap becomes min(value, the cap the handle
+ *                               oake_create derived from cfg.max_batch and cfg.pass_rows (default: ~25 600 token
+ *                               rows).  set: a bound >= 1; the cap becomes min(value, the cap the handle
  *                               was created with: the workspace is sized for that) — what the reference's
  *                               `mini_batch_size` is: a memory bound on one pass [REF oadp/oake/objects.py:321-331].  A call's crops are cut into
  *                               equal passes under the cap.
+ *   OAKE_OPT_QKV_WALK           the fused qkv + attention kernel's tile walk inside an XCD (csrc/qkv_attn_obj.hip,
+ *                               walk_decode): n > 0 = head blocks of n heads x group blocks of 32 / n groups (a group =
+ *                               a crop, or four images), so that one round of an XCD's 32 blocks streams n x 295 KB of
+ *                               the in-projection past 32 / n groups' rows instead of all 3.5 MB of it; 0 = group-major
+ *                               (every head of 2.67 groups per round: the order of round 5).  Placement only: results
+ *                               are identical.  Head counts that n does not divide fall back to 0.  Default 4.
  */
 enum {
   OAKE_OPT_CLS_LAST = 1,
@@ -350,7 +362,8 @@ enum {
   OAKE_OPT_CU_COUNT = 6,
   OAKE_OPT_FUSE_ATTN_OUT = 7,
   OAKE_OPT_PASS_CROPS = 8,
-  OAKE_OPT_FUSE_QKV_ATTN = 9
+  OAKE_OPT_FUSE_QKV_ATTN = 9,
+  OAKE_OPT_QKV_WALK = 10
 };
 OAKE_API int oake_set_option(oake_handle* h, int option, int value);
 OAKE_API int oake_get_option(const oake_handle* h, int option, int* value);

@@ -119,6 +119,9 @@ OAKE_API int oake_debug_gemm_resid16(const void* d_a, const void* d_w, const flo
 /* GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside), n < 0 = M slabs of
  * -n tiles (column-major inside). */
 OAKE_API int oake_debug_set_gemm_panel(int panel);
+/* Tile walk of the fused qkv + attention kernel for the calling thread's oake_debug_ln_qkv_attn_* calls: heads per head
+ * block (OAKE_OPT_QKV_WALK's meaning; 0 = group-major).  Placement only: the results do not depend on it. */
+OAKE_API int oake_debug_set_qkv_walk(int heads_per_block);
 /* Debug: device buffer of 4608 uint64 receiving per-tile cycle stamps of the production GEMM
  * (entry, tile start, epilogue start, epilogue end; then per-block wall-clock entry/exit), or NULL. */
 OAKE_API int oake_debug_set_gemm_trace(void* d_trace);

@@ -15,7 +15,8 @@ OAKE_OPT_CU_COUNT = 6
 OAKE_OPT_FUSE_ATTN_OUT = 7
 OAKE_OPT_PASS_CROPS = 8
 OAKE_OPT_FUSE_QKV_ATTN = 9
-ABI_VERSION = 3
+OAKE_OPT_QKV_WALK = 10
+ABI_VERSION = 4
 
 # OAKE_LIB: kernel-experiment builds (tools/); the product always loads the in-tree library
 LIB_PATH = pathlib.Path(os.environ.get('OAKE_LIB') or pathlib.Path(__file__).resolve().parent / 'liboake_hip.so')
@@ -24,7 +25,7 @@ LIB_PATH = pathlib.Path(os.environ.get('OAKE_LIB') or pathlib.Path(__file__).res
 class OakeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'image_size', 'patch_size', 'stride', 'padding', 'width', 'layers', 'heads', 'mlp_dim',
-        'embed_dim', 'compute_dtype', 'max_batch', 'residual_dtype')]
+        'embed_dim', 'compute_dtype', 'max_batch', 'residual_dtype', 'pass_rows')]
 
 
 class ProfileEntry(C.Structure):
@@ -94,13 +95,15 @@ DEBUG_SIGNATURES = {
     'oake_debug_lab_build': (_I, []),
     'oake_debug_gemm_resid16': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_set_gemm_panel': (_I, [_I]),
+    'oake_debug_set_qkv_walk': (_I, [_I]),
     'oake_debug_set_gemm_trace': (_I, [_VP]),
     'oake_debug_read_weight16': (_I, [_VP, C.c_char_p, _VP, C.c_size_t]),
 }
 
 _lib = None
 _lab = None
-LAB_PATH = pathlib.Path(__file__).resolve().parent / 'liboake_hip_lab.so'
+# OAKE_LAB_LIB: a lab-flavoured experiment build (tools/ only), as OAKE_LIB for the product
+LAB_PATH = pathlib.Path(os.environ.get('OAKE_LAB_LIB') or pathlib.Path(__file__).resolve().parent / 'liboake_hip_lab.so')
 
 
 class OakeTextConfig(C.Structure):

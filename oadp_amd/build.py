@@ -18,8 +18,10 @@ ROOT = pathlib.Path(__file__).resolve().parent
 CSRC = ROOT / 'csrc'
 BUILD = CSRC / '_build'
 LIB = ROOT / 'liboake_hip.so'
-SOURCES = ['gemm.hip', 'attention.hip', 'qkv_attn.hip', 'qkv_attn_obj.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
-LAB_ONLY_SOURCES = ['attn_out.hip']  # kernels that lost their A/B: liboake_hip_lab.so only
+SOURCES = ['gemm.hip', 'attention.hip', 'qkv_attn_obj.hip', 'rowops.hip', 'resample.hip', 'jpeg.hip', 'api.hip']
+# kernels that lost their A/B: liboake_hip_lab.so only (attn_out: attention + out_proj in one kernel, round 4; qkv_attn: the
+# three-images-per-160-row-tile form of the fused qkv + attention kernel, round 5 — the four-image form of qkv_attn_obj.hip won)
+LAB_ONLY_SOURCES = ['attn_out.hip', 'qkv_attn.hip']
 HEADERS = ['common.h', 'kernels.h', 'attention_head.inc', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'
 # instantiations that may spill: the s_memtime-stamped measurement build of attn_out (oake_debug_attn_out_trace), and
@@ -69,7 +71,8 @@ def _compile(src: str, force: bool, lab: bool = False) -> pathlib.Path:
     obj = build / (src + '.o')
     stamp = build / (src + '.sha')
     extra = ['-DOAKE_LAB=1'] if lab else []
-    dig = _digest([s] + [CSRC / hd for hd in HEADERS] + ([CSRC / i for i in LAB_INCLUDES] if lab else [])) + str(lab)
+    lab_inc = lab or '-DOAKE_LAB=1' in FLAGS
+    dig = _digest([s] + [CSRC / hd for hd in HEADERS] + ([CSRC / i for i in LAB_INCLUDES] if lab_inc else [])) + str(lab)
     if not force and obj.exists() and stamp.exists() and stamp.read_text() == dig:
         return obj
     cmd = [_hipcc(), *FLAGS, *extra, '-Rpass-analysis=kernel-resource-usage', '-c', str(s), '-o', str(obj)]
@@ -116,6 +119,16 @@ def build_library(force: bool = False, verbose: bool = False, lab: bool = True) 
     if lab and not os.environ.get('OAKE_LIB_OUT'):
         jobs += [(src, True) for src in SOURCES if src in ('gemm.hip', 'attention.hip', 'api.hip')]
         jobs += [(src, True) for src in LAB_ONLY_SOURCES]
+    if os.environ.get('OAKE_LIB_OUT') and '-DOAKE_LAB=1' in FLAGS:
+        # an experiment build of the LAB flavour (OAKE_EXTRA_FLAGS='-DOAKE_LAB=1 ...'): one library, every source with the
+        # flag, the lab-only kernels linked in; tools load it through OAKE_LAB_LIB (oadp_amd._lib.load_lab)
+        jobs += [(src, False) for src in LAB_ONLY_SOURCES]
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            objs = list(ex.map(lambda j: _compile(j[0], force, j[1]), jobs))
+        _link(objs, LIB, force)
+        if verbose:
+            print(f'built {LIB} (lab flavour)')
+        return LIB
     with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(lambda j: _compile(j[0], force, j[1]), jobs))
     prod = objs[:len(SOURCES)]

@@ -27,6 +27,21 @@ from .. import _lib
 from .preprocess import Preprocess
 from .settings import settings
 
+
+def _pass_config(max_batch: int, env) -> tuple[int, int]:
+    """(oake_config.max_batch, oake_config.pass_rows) from the caller's max_batch and the two experiment variables the
+    LIBRARY used to read itself (the pass size decides output rounding, so it travels through the
+    ABI's arguments): OAKE_PASS_ROWS = token rows per encoder pass (0 = no row cap; default: the library's 25 600),
+    OAKE_PASS_CROPS = the cap in crops directly (then no row cap beside it)."""
+    rows = env.get('OAKE_PASS_ROWS')
+    crops = env.get('OAKE_PASS_CROPS')
+    if crops not in (None, ''):
+        return max(1, min(int(max_batch), int(crops))), -1
+    if rows in (None, ''):
+        return int(max_batch), 0
+    return int(max_batch), (int(rows) if int(rows) > 0 else -1)
+
+
 _TORCH2OAKE = {torch.float32: _lib.OAKE_F32, torch.float16: _lib.OAKE_F16,
                torch.bfloat16: _lib.OAKE_BF16}
 
@@ -169,7 +184,7 @@ class VisionTransformer(_HookPoint):
                    gemm_panel=_lib.OAKE_OPT_GEMM_PANEL, attention_variant=_lib.OAKE_OPT_ATTENTION_VARIANT,
                    patch_direct=_lib.OAKE_OPT_PATCH_DIRECT, cu_count=_lib.OAKE_OPT_CU_COUNT,
                    fuse_attn_out=_lib.OAKE_OPT_FUSE_ATTN_OUT, pass_crops=_lib.OAKE_OPT_PASS_CROPS,
-                   fuse_qkv_attn=_lib.OAKE_OPT_FUSE_QKV_ATTN)
+                   fuse_qkv_attn=_lib.OAKE_OPT_FUSE_QKV_ATTN, qkv_walk=_lib.OAKE_OPT_QKV_WALK)
 
     def set_option(self, name: str, value: int) -> None:
         """Per-model kernel-selection switch (``oake_set_option`` on every lane's handle, now and for
@@ -255,7 +270,7 @@ class VisionTransformer(_HookPoint):
         pos = self.positional_embedding
         pos = pos.data if isinstance(pos, torch.nn.Parameter) else pos
         key = (device_index, stride, pad, pos.data_ptr(), tuple(pos.shape), self.compute_dtype,
-               self.residual_dtype, self.max_batch)
+               self.residual_dtype, self.max_batch, _pass_config(self.max_batch, os.environ))
         cur = self._lanes.get(self.lane)
         if cur is not None and key == cur[1]:
             return cur[0]
@@ -271,7 +286,7 @@ class VisionTransformer(_HookPoint):
         cfg.mlp_dim, cfg.embed_dim = self.mlp_dim, self.output_dim
         cfg.compute_dtype = _TORCH2OAKE[self.compute_dtype]
         cfg.residual_dtype = _TORCH2OAKE[self.residual_dtype]
-        cfg.max_batch = self.max_batch
+        cfg.max_batch, cfg.pass_rows = _pass_config(self.max_batch, os.environ)
         h = C.c_void_p()
         _lib.check(lib, None, lib.oake_create(C.byref(cfg), device_index, C.byref(h)), 'oake_create')
         try:
@@ -320,10 +335,10 @@ class VisionTransformer(_HookPoint):
             self._apply_pass_limit(h)
 
     def _apply_pass_limit(self, h) -> None:
-        if self._pass_limit is None:
-            return
-        _lib.check(self._lib, h, self._lib.oake_set_option(h, _lib.OAKE_OPT_PASS_CROPS, self._pass_limit),
-                   'oake_set_option')
+        # None: back to the cap the handle was created with (the library clamps the value to that cap), so a user of the
+        # same model after an objects sweep — whose mini_batch_size lowered it — runs its own pass size again
+        limit = self._pass_limit if self._pass_limit is not None else 2 ** 30
+        _lib.check(self._lib, h, self._lib.oake_set_option(h, _lib.OAKE_OPT_PASS_CROPS, limit), 'oake_set_option')
 
     def close(self) -> None:
         for h, _ in self._lanes.values():

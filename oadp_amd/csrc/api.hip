@@ -427,12 +427,13 @@ int create_impl(const oake_config* cfg, int device, oake_handle** out, bool text
     // Cache between the kernel that writes them and the one that reads them.  Measured in one session
     // (tools/mb_sweep.sh, profiles/r04/pass_rows_sweep.log): objects mode (L = 197) 25.4 / 26.0 / 26.2 k crops/s at
     // 512 / 256 / 128 crops per pass, blocks mode (L = 50) 111.0 / 108.3 / 98.4 k at 512 / 256 / 128 and 108.5 /
-    // 105.9 at 1024 / 1728 (round 3) — both best at ~25 k rows.  OAKE_PASS_ROWS overrides the target (0: no limit).
-    long rows = 25600;
-    if (const char* e = std::getenv("OAKE_PASS_ROWS")) rows = std::atol(e);
+    // 105.9 at 1024 / 1728 (round 3) — both best at ~25 k rows.
+    // cfg.pass_rows names the target (0: this default; < 0: no row cap).  No environment variable is read here: the
+    // pass size decides output rounding, and an ABI library takes such things through its arguments (the Python host
+    // maps OAKE_PASS_ROWS / OAKE_PASS_CROPS onto the config, oadp_amd/clip/model.py).
+    const long rows = c.pass_rows == 0 ? 25600 : c.pass_rows;
     if (rows > 0) {
-      long per = std::max<long>(32, rows / h->tokens / 32 * 32);
-      if (const char* e = std::getenv("OAKE_PASS_CROPS")) per = std::max<long>(1, std::atol(e));  // (experiments)
+      const long per = std::max<long>(32, rows / h->tokens / 32 * 32);
       if (per < c.max_batch) h->cfg.max_batch = c.max_batch = (int)per;
     }
   }
@@ -647,6 +648,13 @@ int oake_load_tensor(oake_handle* h, const char* name, const float* data, size_t
       HIP_TRY(h, hipStreamSynchronize(0));
     } else if (leaf == "attn.out_proj.weight") {
       W16(w.out_w, C * C);
+#if OAKE_LAB
+      // (a reload after OAKE_OPT_FUSE_ATTN_OUT was switched on: attn_out_kernel's fragment-order copy follows the weight)
+      if (w.out_wp) {
+        HIP_TRY(h, launch_permute_out_w(h->dt16, w.out_w, w.out_wp, 0));
+        HIP_TRY(h, hipStreamSynchronize(0));
+      }
+#endif
     }
     else if (leaf == "attn.out_proj.bias") F32(w.out_b, C);
     else if (leaf == "mlp.c_fc.weight") {
@@ -847,6 +855,15 @@ int mlp_rows(oake_handle* h, hipStream_t s, const LayerW& w, size_t r0, int M, c
   return gemm(h, s, n_pr.c_str(), resid, hb, w.proj_w, w.proj_b, xr, M, C, F, C, nullptr, nullptr, r0);
 }
 
+// The three-images-per-160-row-tile form (csrc/qkv_attn.hip) lost its A/B to the four-image form in round 5 and no shipped
+// configuration reaches it (51 <= L <= 53 only): it is in liboake_hip_lab.so alone; the product runs such sequence lengths
+// through the two launches (LN-folded qkv GEMM + attention kernel).
+#if OAKE_LAB
+inline bool tri_supported(int L, int heads, int width, int n) { return qkv_attn_supported(L, heads, width, n); }
+#else
+inline bool tri_supported(int, int, int, int) { return false; }
+#endif
+
 // which fused form a handle's geometry takes: the 208-row tile kernel (csrc/qkv_attn_obj.hip: objects mode, or four images
 // of <= 50 tokens per tile) or the 160-row one (csrc/qkv_attn.hip: three images of <= 53 tokens; fuse_qkv_attn == 2 asks
 // for it where both apply) — they read the folded in-projection in different column orders
@@ -860,15 +877,23 @@ bool qkv_perm_is_obj(const oake_handle* h) {
 // the head-major copies of the folded in-projection (qkv_attn.hip): made on the first pass that takes the fused path
 int ensure_qkv_perm(oake_handle* h) {
   if (h->qkv_perm) return OAKE_OK;
+  // (reached from check_ready with the fold already done — the option toggled after the first encode — on whatever device
+  // the calling thread last used: the allocations and the permute launches below belong on the handle's)
+  HIP_TRY(h, hipSetDevice(h->device));
   const size_t C = h->cfg.width;
   for (auto& w : h->layers) {
     if (!w.in_wfp) HIP_TRY(h, hipMalloc(&w.in_wfp, 3 * C * C * 2));
     if (!w.in_csp) HIP_TRY(h, hipMalloc((void**)&w.in_csp, 3 * C * 4));
     if (!w.in_bfp) HIP_TRY(h, hipMalloc((void**)&w.in_bfp, 3 * C * 4));
-    if (qkv_perm_is_obj(h))  // (a handle has ONE geometry)
+    if (qkv_perm_is_obj(h)) {  // (a handle has ONE geometry)
       HIP_TRY(h, launch_permute_qkv_obj(w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
-    else
+    } else {
+#if OAKE_LAB
       HIP_TRY(h, launch_permute_qkv(h->dt16, w.in_wf, w.in_bf, w.in_cs, w.in_wfp, w.in_bfp, w.in_csp, (int)C, 0));
+#else
+      return fail(h, OAKE_ERR_STATE, "qkv_attn: the three-image form is in the lab build only");
+#endif
+    }
   }
   HIP_TRY(h, hipStreamSynchronize(0));
   h->qkv_perm = true;
@@ -879,7 +904,7 @@ int ensure_qkv_perm(oake_handle* h) {
 bool fuses_qkv_attn(const oake_handle* h, int nb) {
   if (!(h->fuse_qkv_attn && h->stat_fused && !h->text && h->xdt != DT_F32)) return false;
   if (uses_qkv_attn_quad(h)) return qkv_attn_quad_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
-  return !qkv_perm_is_obj(h) && qkv_attn_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
+  return !qkv_perm_is_obj(h) && tri_supported(h->cur_len, h->cfg.heads, h->cfg.width, nb);
 }
 
 int main_in_proj(oake_handle* h, hipStream_t s, const LayerW& w, int T, bool kv_only) {
@@ -924,10 +949,14 @@ int main_qkv_attn(oake_handle* h, hipStream_t s, const LayerW& w, int nb) {
                               &h->opts, s, nullptr));
     return mlp_rows(h, s, w, 0, T, "");
   }
+#if OAKE_LAB
   RUNK(h, s, "qkv_attn", 2.0 * T * 3 * C * C + 4.0 * nb * h->cfg.heads * (double)L * L * 64, 0.0,
        launch_qkv_attn(h->dt16, h->x, w.in_wfp, w.in_bfp, w.in_csp, h->rowpart, np, h->att, nb, L, h->cfg.heads,
                        &h->opts, s));
   return mlp_rows(h, s, w, 0, T, "");
+#else
+  return fail(h, OAKE_ERR_STATE, "qkv_attn: the three-image form is in the lab build only");
+#endif
 }
 
 
@@ -962,7 +991,7 @@ int check_ready(oake_handle* h) {
   }
   h->folded = true;
   if (h->fuse_qkv_attn && !h->text && h->xdt != DT_F32 && !h->qkv_perm &&
-      (qkv_attn_supported(h->tokens, h->cfg.heads, h->cfg.width, 1) || qkv_perm_is_obj(h)))
+      (tri_supported(h->tokens, h->cfg.heads, h->cfg.width, 1) || qkv_perm_is_obj(h)))
     return ensure_qkv_perm(h);
   return OAKE_OK;
 }
@@ -1794,6 +1823,12 @@ int oake_debug_ln_gemm16(const void* d_x, const float* d_w32, const float* d_gam
 int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
                            const float* d_bias, void* d_out, int n_img, int l, int heads, int dtype16, void* d_trace,
                            int repeats, void* stream) {
+#if !OAKE_LAB
+  // (the three-image form lost its A/B to the four-image one — DESIGN.md appendix, round 5 — and lives in liboake_hip_lab.so only)
+  (void)d_x; (void)d_w32; (void)d_gamma; (void)d_beta; (void)d_bias; (void)d_out; (void)n_img; (void)l; (void)heads;
+  (void)dtype16; (void)d_trace; (void)repeats; (void)stream;
+  return OAKE_ERR_UNSUPPORTED;
+#else
   const int C = heads * 64, n = 3 * C, m = n_img * l;
   if (!d_x || !d_w32 || !d_gamma || !d_beta || !d_bias || !d_out || n_img < 1) return OAKE_ERR_INVALID;
   if (!qkv_attn_supported(l, heads, C, n_img)) return OAKE_ERR_UNSUPPORTED;
@@ -1817,6 +1852,7 @@ int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_g
   (void)hipFree(wf); (void)hipFree(wp); (void)hipFree(cs); (void)hipFree(bf); (void)hipFree(csp); (void)hipFree(bfp);
   (void)hipFree(part);
   return dbg(e);
+#endif
 }
 
 int oake_debug_ln_qkv_attn_quad(const void* d_x, const float* d_w32, const float* d_gamma, const float* d_beta,
@@ -1958,6 +1994,12 @@ int oake_debug_set_gemm_panel(int panel) {
   return OAKE_OK;
 }
 
+int oake_debug_set_qkv_walk(int heads_per_block) {
+  if (heads_per_block < 0 || heads_per_block > 32) return OAKE_ERR_INVALID;
+  t_debug_opts.qkv_walk = heads_per_block;
+  return OAKE_OK;
+}
+
 int oake_debug_set_gemm_trace(void* d_trace) {
   t_debug_opts.gemm_trace = reinterpret_cast<unsigned long long*>(d_trace);
   return OAKE_OK;
@@ -2022,11 +2064,20 @@ int oake_set_option(oake_handle* h, int option, int value) {
 #endif
     case OAKE_OPT_FUSE_QKV_ATTN: {
       if (value < 0 || value > 2) return fail(h, OAKE_ERR_INVALID, "OAKE_OPT_FUSE_QKV_ATTN: 0, 1 or 2");
+#if !OAKE_LAB
+      if (value == 2)
+        return fail(h, OAKE_ERR_INVALID, "OAKE_OPT_FUSE_QKV_ATTN = 2 (the three-image form, csrc/qkv_attn.hip) is in the lab "
+                                         "build liboake_hip_lab.so only");
+#endif
       const bool was_obj = qkv_perm_is_obj(h);
       h->fuse_qkv_attn = value;
       if (qkv_perm_is_obj(h) != was_obj) h->qkv_perm = false;  // (the other form's column order: permuted again on the next pass)
       return OAKE_OK;
     }
+    case OAKE_OPT_QKV_WALK:
+      if (value < 0 || value > 32) return fail(h, OAKE_ERR_INVALID, "OAKE_OPT_QKV_WALK: 0 (group-major) or heads per head block, 1 .. 32");
+      h->opts.qkv_walk = value;
+      return OAKE_OK;
     case OAKE_OPT_PASS_CROPS:
       if (h->text) return fail(h, OAKE_ERR_INVALID, "pass_crops: vision handles only");
       if (value < 1) return fail(h, OAKE_ERR_INVALID, "pass_crops must be >= 1");
@@ -2048,6 +2099,7 @@ int oake_get_option(const oake_handle* h, int option, int* value) {
     case OAKE_OPT_FUSE_ATTN_OUT: *value = h->fuse_attn_out; return OAKE_OK;
     case OAKE_OPT_PASS_CROPS: *value = h->cfg.max_batch; return OAKE_OK;
     case OAKE_OPT_FUSE_QKV_ATTN: *value = h->fuse_qkv_attn; return OAKE_OK;
+    case OAKE_OPT_QKV_WALK: *value = h->opts.qkv_walk; return OAKE_OK;
     default: return OAKE_ERR_INVALID;
   }
 }

@@ -139,6 +139,13 @@ struct TileMap {
 #ifndef OAKE_RESID_INIT
 #define OAKE_RESID_INIT 1
 #endif
+// Measurement builds of the persistent kernel's K loop (WRONG results; tools/kloop_ablate.sh, profiles/r06/kloop_ablation.md):
+// which resource a K-tile's time follows.  Bits: 1 = half of the fragment reads (the odd fragments are copies of the even
+// ones: 5 of 9 ds_read_b128 per kk), 2 = half of the LDS-DMA pieces (the odd pieces of a DMA wave are never issued: 7 of
+// 13), 4 = half of the MFMAs (the odd column tiles are skipped).  Barriers, waits and phases are unchanged in every form.
+#ifndef OAKE_KLOOP_ABLATE
+#define OAKE_KLOOP_ABLATE 0
+#endif
 template <typename V>
 __device__ __forceinline__ V resid_load16(const V* p) {
 #if OAKE_RESID_NT
@@ -1002,7 +1009,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       const size_t _koff = (size_t)s_kt * (BK * 2);                                          \
       const size_t _koffa = ep.patch_S != 0 ? patch_koff(s_kt, ep.patch_S, ep.patch_P, ep.patch_H) : _koff; \
       _Pragma("unroll") for (int _j = (j0_); _j < (j1_); ++_j)                               \
-          if (!A32 || _j >= kAPieces) {                                                      \
+          if ((!A32 || _j >= kAPieces) && !((OAKE_KLOOP_ABLATE & 2) && !A32 && (_j & 1))) {  \
             if (_j < kAPieces)                                                               \
               __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koffa),                \
                                                (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0,           \
@@ -1032,7 +1039,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 #define OAKE_VMCNT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
     constexpr int Q1 = (NPL + 3) / 4, Q2 = (2 * NPL + 3) / 4, Q3 = (3 * NPL + 3) / 4;
     // vmcnt entries one K-tile's worth of this wave's requests occupies
-    constexpr int kPerKt = A32 ? (NPL - kAPieces) + 2 * kAPieces : NPL;
+    constexpr int kPerKt = A32 ? (NPL - kAPieces) + 2 * kAPieces : (OAKE_KLOOP_ABLATE & 2) ? (NPL + 1) / 2 : NPL;
     static_assert(kPerKt <= 63, "vmcnt immediate");
     set_src(0);
     a32_set_src(0);
@@ -1170,9 +1177,11 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   do {                                                                                      \
     const char* _st = smem + (buf_) * kStageBytes;                                          \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                          \
-        af[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + (koff_)); \
+        af[i] = ((OAKE_KLOOP_ABLATE & 1) && (i & 1)) ? af[i - 1]                            \
+                : *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + (koff_)); \
     _Pragma("unroll") for (int i = 0; i < NI; ++i)                                          \
-        bf[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + (koff_)); \
+        bf[i] = ((OAKE_KLOOP_ABLATE & 1) && (i & 1)) ? bf[i - 1]                            \
+                : *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + (koff_)); \
   } while (0)
 // A compute wave raises its issue priority for its MFMA phase (s_setprio 1 .. 0 around the cluster: while it issues
 // MFMAs its SIMD's other compute wave reads fragments and the DMA wave issues pieces).  Round 1 had only tried static
@@ -1190,7 +1199,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     OAKE_PRIO(1);                                                                           \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                       \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                   \
-            acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);                        \
+            if (!((OAKE_KLOOP_ABLATE & 4) && (ni & 1)))                                     \
+              acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);                      \
     if (!PH2) OAKE_PRIO(0);                                                                 \
   } while (0)
   // (after the epilogue, not while it consumes the rows: zeroed early, the accumulators would stay
@@ -1235,14 +1245,15 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       vec8 af1[MI], bf1[NI];
       {
         const char* _st = smem + c_buf * kStageBytes;
+        constexpr bool kHalfReads = (OAKE_KLOOP_ABLATE & 1) != 0;  // (measurement build: odd fragments = copies)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff0);
+        for (int i = 0; i < MI; ++i) af[i] = (kHalfReads && (i & 1)) ? af[i - 1] : *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff0);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) bf[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff0);
+        for (int i = 0; i < NI; ++i) bf[i] = (kHalfReads && (i & 1)) ? bf[i - 1] : *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff0);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af1[i] = *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff1);
+        for (int i = 0; i < MI; ++i) af1[i] = (kHalfReads && (i & 1)) ? af1[i - 1] : *reinterpret_cast<const vec8*>(_st + a_base + i * 16 * kRowBytes + koff1);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) bf1[i] = *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff1);
+        for (int i = 0; i < NI; ++i) bf1[i] = (kHalfReads && (i & 1)) ? bf1[i - 1] : *reinterpret_cast<const vec8*>(_st + b_base + i * 16 * kRowBytes + koff1);
       }
       OAKE_LGKM0();
       OAKE_BAR();
@@ -1250,7 +1261,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf1[ni], af1[mi], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni)
+          if (!((OAKE_KLOOP_ABLATE & 4) && (ni & 1))) acc[mi][ni] = T16<T>::mfma(bf1[ni], af1[mi], acc[mi][ni]);
       OAKE_PRIO(0);
     } else {
     OAKE_LOAD_FRAGS(c_buf, koff0);
@@ -1566,6 +1578,9 @@ hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
   if constexpr (EpiTraits<EPI>::kNone || EpiTraits<EPI>::kRaw) {  // measurement epilogues: persistent kernels only
     if (variant == 8) return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);
     if (variant == 11) return launch_duo<T, EPI, 160, 128>(a, s);
+    if constexpr (EpiTraits<EPI>::kNone) {  // (9: the K loop alone in the production schedule, two long phases per K-tile)
+      if (variant == 9) return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+    }
     return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
   } else
   switch (variant) {

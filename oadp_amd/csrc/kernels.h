@@ -31,6 +31,7 @@ enum GemmEpi {
 // Kernel-selection switches of one caller (a handle, or the calling thread's handle-less oake_debug_* entry
 // points).  No process-wide state: two handles / lanes never see each other's settings.
 constexpr int kAttentionVariantDefault = 159;  // attention.hip: bits 1 | 2 | 4 | 8 | 16 | 128
+constexpr int kQkvWalkDefault = 4;             // qkv_attn_obj.hip: tile walk in head blocks of 4 (0 = group-major)
 
 struct LaunchOpts {
   int gemm_variant = -1;   // -1 = automatic per shape, else a forced tile configuration (csrc/gemm.hip)
@@ -39,6 +40,7 @@ struct LaunchOpts {
   int attention_variant = kAttentionVariantDefault;  // bits: see oake_debug_set_attention_variant
   int cu_count = 0;        // compute units the launch stream may use (0 = all of the device): a handle driven on a
                            // CU-masked stream (hipExtStreamCreateWithCUMask) sizes its persistent grids to that
+  int qkv_walk = kQkvWalkDefault;  // fused qkv + attention kernel: heads per head block of the tile walk (walk_decode)
 };
 
 struct GemmArgs {

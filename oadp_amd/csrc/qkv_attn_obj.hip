@@ -66,8 +66,37 @@ struct QkvAttnObjParams {
   int n_img, L, H, T;     // crops, tokens per crop, heads, T = n_img * L = first object-token row
   const void* mask;       // [n_img, L - 1], 1 = background
   int mask_f16;
+  int walk_hq, walk_gq;   // tile walk (walk_decode): head blocks of walk_hq heads x group blocks of walk_gq groups; 0 = group-major
   unsigned long long* trace;
 };
+
+// Tile walk.  A tile is (group, head) — group = a crop (objects) or four images (QUAD).  The flat order t -> (group, head)
+// decides what an XCD's 32 co-resident blocks stream through its 4 MiB L2 (XCD x owns a contiguous range of t, block
+// b / 8 of it takes every 32nd tile): group-major (t = group * H + head) puts 2.67 groups x ALL heads side by side, i.e.
+// the whole folded in-projection (3 C^2 = 3.5 MB) passes every XCD's L2 once per round of 32 tiles — measured reads
+// 104 MB per launch for 23 MB algorithmic (globals: 8 XCDs x 3 rounds x 3.5 MB + x).  Blocked: group blocks of GQ groups
+// (outer), inside them head blocks of HQ heads, inside those (group, head) — one round of an XCD is then GQ groups x HQ
+// heads: HQ x 295 KB of W beside GQ x (rows x 1.5 KB) of x, and the x rows of a group block stay in the L2 while its H / HQ
+// head blocks pass.  HQ x GQ = 32 = the blocks per XCD at 256 CUs.  [REF oadp/oake/globals.py:57; objects.py:223-247: the
+// reference's attention has no such order; this is placement only, the results do not depend on it]
+__device__ __forceinline__ void walk_decode(int t, int G, int H, int HQ, int GQ, int& grp, int& head) {
+  if (HQ <= 0 || H % HQ != 0) {
+    grp = t / H;
+    head = t - grp * H;
+    return;
+  }
+  const int per_gb = GQ * H;
+  const int gb = t / per_gb;
+  int r = t - gb * per_gb;
+  const int left = G - gb * GQ;
+  const int gl = left < GQ ? left : GQ;  // groups of this block (the last one may be short)
+  const int per_hb = gl * HQ;
+  const int hb = r / per_hb;
+  r -= hb * per_hb;
+  const int g = r / HQ;
+  grp = gb * GQ + g;
+  head = hb * HQ + (r - g * HQ);
+}
 
 template <typename T>
 struct ObjTask {
@@ -506,8 +535,8 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
     QO_BAR();  // X4: v is in LDS (over the q region)
     if (stamp) QO_STAMP(LATE ? 1 : 0, ti, 6);
     {
-      const int tile = xb + xslot + ti * per_xcd;
-      const int img = tile / H, head = tile - img * H;
+      int img, head;
+      walk_decode(xb + xslot + ti * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, img, head);
       if constexpr (QUAD) {
         const int row_first = img * 4 * L;  // (img: the tile's group of four images)
         quad_task_pv<T, 1>(qtask, qs, wid, L, reinterpret_cast<char*>(out + (size_t)row_first * C + head * kHeadDim),
@@ -570,8 +599,8 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
       return rr < L ? img * L + rr : p.T + img;
     };
     auto set_src = [&](int tile_i) {
-      const int tile = xb + xslot + tile_i * per_xcd;
-      const int img = tile / H, head = tile - img * H;
+      int img, head;
+      walk_decode(xb + xslot + tile_i * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, img, head);
 #pragma unroll
       for (int j = 0; j < NPLMAX; ++j) {
         int ii = lw + NL * j;
@@ -625,9 +654,7 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
     constexpr int RPW = LBM / NL;  // 52 rows per DMA wave, one per lane
     float st_rstd = 0.f, st_shift = 0.f;
     auto tile_of = [&](int tile_i, int& img, int& head) {
-      const int tile = xb + xslot + tile_i * per_xcd;
-      img = tile / H;
-      head = tile - img * H;
+      walk_decode(xb + xslot + tile_i * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, img, head);
     };
     for (int g = 0; g < total; ++g) {
       if (d_kt == 0 && lane < RPW) {
@@ -809,6 +836,10 @@ static hipError_t qkv_attn_obj_launch_t(const void* x, const void* wp, const flo
   p.inv_k = 1.0f / (float)C;
   p.n_img = n_img; p.L = L; p.H = heads; p.T = n_img * L;
   p.mask = mask; p.mask_f16 = mask_dtype == DT_F16 ? 1 : 0;
+  // head blocks of qkv_walk heads (LaunchOpts: 0 = group-major), group blocks of 32 / qkv_walk groups
+  const int hq = opts ? opts->qkv_walk : kQkvWalkDefault;
+  p.walk_hq = hq > 0 && heads % hq == 0 ? hq : 0;
+  p.walk_gq = p.walk_hq > 0 ? (32 / p.walk_hq > 0 ? 32 / p.walk_hq : 1) : 0;
   p.trace = trace;
   const int ntiles = (QUAD ? (n_img + 3) / 4 : n_img) * heads;
   int grid = (num_cu / 8) * 8;

@@ -75,6 +75,10 @@ __global__ void resample_coeffs_kernel(const ResampleJob* __restrict__ jobs, int
       kq = (int)(-0.5 + w * (1 << kPrecisionBits));
     else
       kq = (int)(0.5 + w * (1 << kPrecisionBits));
+    // tap() multiplies 24-bit factors: |k| < 2^23 always holds for the bicubic window (|w| < 2, see tap) — a coefficient
+    // outside it could only come from a degenerate window sum and must not be truncated silently
+    constexpr int kMaxCoef = (1 << 23) - 1;
+    kq = kq > kMaxCoef ? kMaxCoef : (kq < -kMaxCoef ? -kMaxCoef : kq);
     k_out[x] = kq;
   }
   b_out[0] = xmin;
@@ -86,8 +90,12 @@ __device__ __forceinline__ uint8_t clip8(int v) {
   return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-// One filter tap: pixel (0 .. 255) x fixed-point coefficient.  Pillow's 8-bit coefficients are round(w * 2^22) with |w| <= 1
-// (normalize_coeffs_8bpc, PRECISION_BITS = 22), so both factors fit 24 signed bits and the product is v_mul_i32_i24 /
+// One filter tap: pixel (0 .. 255) x fixed-point coefficient.  Pillow's 8-bit coefficients are round(w * 2^22)
+// (normalize_coeffs_8bpc, PRECISION_BITS = 22) with |w| < 2, i.e. |k| < 2^23: a normalised bicubic weight EXCEEDS 1 where
+// the window is cut at an image border (~1.125 when the negative lobe of one side is clipped away), and the bound that
+// matters is the 24-bit one — resample_coeffs_kernel clamps to it (never reached by the bicubic filter; a degenerate
+// window sum must not wrap silently), tests/test_resample_gpu.py checks max |k| over border windows.  So both factors fit
+// 24 signed bits and the product is v_mul_i32_i24 /
 // v_mad_i32_i24 — full-rate instructions — where a 32-bit `*` compiles to v_mul_lo_u32 / v_mad_u64_u32 at a quarter of the
 // rate (68 + 44 of them per thread of the horizontal pass: the pass was multiply-bound at 0.12 of the HBM peak).  Same
 // integers: the low 32 bits of the exact product.

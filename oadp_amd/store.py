@@ -142,7 +142,7 @@ def gpu_pci_addresses() -> list[str] | None:
 
 
 def plan_cpus(local_rank: int, local_world: int, allowed: list[int], gpu_pci: list[str] | None = None,
-              sysfs: str = '/sys') -> tuple[list[int], str]:
+              sysfs: str = '/sys', device_index: int | None = None) -> tuple[list[int], str]:
     """The CPUs rank `local_rank` of a node's `local_world` ranks should run on, and how they were chosen.
 
     Topology-aware: rank r drives GPU r mod #GPUs; that GPU's NUMA node is read from
@@ -151,7 +151,14 @@ def plan_cpus(local_rank: int, local_world: int, allowed: list[int], gpu_pci: li
     cores at a time — SMT siblings (<sysfs>/devices/system/cpu/cpu<c>/topology/thread_siblings_list) stay together,
     whatever the numbering (siblings at +N/2 is the usual one).  On a two-socket host ranks 4-7 then sit on the
     socket that owns GPUs 4-7, which a split of the logical CPU ids by rank does not give.  Where sysfs is silent
-    (no numa_node, node -1, no cpulist): the contiguous slices of `cpu_slice`."""
+    (no numa_node, node -1, no cpulist): the contiguous slices of `cpu_slice`.
+
+    `device_index` (advisor r05): the HIP device this rank actually drives, where that is not local_rank mod #GPUs —
+    OAKE_LOCAL_SHARDS=n with n below the GPU count picks the device by the GLOBAL shard (shard_device_index).  With the
+    visibility narrowed to ONE GPU per rank (HIP_VISIBLE_DEVICES set per rank: every rank sees its own GPU as device 0)
+    the other ranks' GPUs are unknown: the rank then takes a share of its GPU's node sized for local_world / #nodes
+    ranks (ranks of a node assumed contiguous in rank order) instead of 1 / local_world of it, which left half of each
+    socket idle on a two-socket host."""
     allowed = sorted(allowed)
     if local_world <= 1:
         return allowed, 'single rank: affinity unchanged'
@@ -169,14 +176,26 @@ def plan_cpus(local_rank: int, local_world: int, allowed: list[int], gpu_pci: li
         return n if n >= 0 else None
 
     nodes = [node_of(a) for a in gpu_pci]
-    mine = nodes[local_rank % ng]
+    dev = (device_index if device_index is not None else local_rank) % ng
+    mine = nodes[dev]
     if mine is None:
         return fallback
     t = _read(f'{sysfs}/devices/system/node/node{mine}/cpulist')
     if not t:
         return fallback
     node_cpus = [c for c in _parse_cpulist(t) if c in set(allowed)]
-    sharing = [r for r in range(local_world) if nodes[r % ng] == mine]
+    if ng == 1 and local_world > 1:
+        # one visible GPU per rank: who shares its node cannot be read off the device list
+        n_nodes = 0
+        while _read(f'{sysfs}/devices/system/node/node{n_nodes}/cpulist'):
+            n_nodes += 1
+        per_node = -(-local_world // max(n_nodes, 1))
+        sharing = list(range(per_node))
+        k_of = local_rank % per_node
+    else:
+        # the device each local rank drives: its own where the caller named it, r mod #GPUs for the others
+        sharing = [r for r in range(local_world) if nodes[(dev if r == local_rank else r) % ng] == mine]
+        k_of = sharing.index(local_rank)
     if not node_cpus or len(node_cpus) < len(sharing):
         return fallback
     # whole cores: a core = the set of its hardware threads that are in node_cpus
@@ -188,12 +207,12 @@ def plan_cpus(local_rank: int, local_world: int, allowed: list[int], gpu_pci: li
         grp = [s for s in (_parse_cpulist(sib) if sib else [c]) if s in set(node_cpus) and s not in seen] or [c]
         seen.update(grp)
         cores.append(sorted(grp))
-    k, m = sharing.index(local_rank), len(sharing)
+    k, m = k_of, len(sharing)
     if len(cores) < m:
         return fallback
     part = cores[k * len(cores) // m:(k + 1) * len(cores) // m]
     keep = sorted(c for core in part for c in core)
-    return keep, f'NUMA node {mine} of GPU {local_rank % ng} ({gpu_pci[local_rank % ng]}), share {k + 1} of {m}, whole cores'
+    return keep, f'NUMA node {mine} of GPU {dev} ({gpu_pci[dev]}), share {k + 1} of {m}, whole cores'
 
 
 def pin_cpus(env=None, gpu_pci: list[str] | None = None, sysfs: str = '/sys', apply: bool = True) -> list[int] | None:
@@ -215,7 +234,9 @@ def pin_cpus(env=None, gpu_pci: list[str] | None = None, sysfs: str = '/sys', ap
             gpu_pci = gpu_pci_addresses()
         except Exception:  # noqa: BLE001 — topology is an optimisation, never a reason to fail a run
             gpu_pci = None
-    keep, how = plan_cpus(lr % lw, lw, cpus, gpu_pci, sysfs)
+    # the device this rank really drives (OAKE_LOCAL_SHARDS below the GPU count: by the GLOBAL shard, shard_device_index)
+    dev = shard_device_index(len(gpu_pci), env) if gpu_pci else None
+    keep, how = plan_cpus(lr % lw, lw, cpus, gpu_pci, sysfs, device_index=dev)
     if not keep or len(keep) == len(cpus):
         return None
     if apply:

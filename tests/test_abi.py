@@ -46,8 +46,8 @@ def test_abi_version_and_default_config(lib):
     assert (cfg.image_size, cfg.patch_size, cfg.stride, cfg.padding) == (224, 32, 32, 0)
     assert (cfg.width, cfg.layers, cfg.heads, cfg.mlp_dim, cfg.embed_dim) == (768, 12, 12, 3072, 512)
     assert cfg.compute_dtype == _lib.OAKE_F16 and cfg.max_batch == 256
-    assert cfg.residual_dtype == _lib.OAKE_F16
-    assert C.sizeof(_lib.OakeConfig) == 48
+    assert cfg.residual_dtype == _lib.OAKE_F16 and cfg.pass_rows == 0
+    assert C.sizeof(_lib.OakeConfig) == 52
 
 
 def test_create_rejects_bad_config_without_gpu(lib):
@@ -102,3 +102,28 @@ def test_lab_library_is_a_superset_build_and_the_product_is_smaller(lib):
     for p in (ROOT / 'oadp_amd').rglob('*.py'):
         if p.name not in ('_lib.py', 'build.py'):
             assert 'load_lab' not in p.read_text() and 'liboake_hip_lab' not in p.read_text(), p
+
+
+def test_product_library_reads_no_environment_and_carries_no_shelved_kernel():
+    """(a) the pass size decides output rounding, so nothing inside liboake_hip.so may take it (or
+    anything else) from the process environment — the library imports no getenv; the Python host maps OAKE_PASS_ROWS /
+    OAKE_PASS_CROPS onto oake_config (clip/model.py::_pass_config).  (b) the three-image fused kernel (csrc/qkv_attn.hip)
+    lost its A/B and is linked into the lab build only."""
+    und = subprocess.run(['nm', '-D', '--undefined-only', str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert 'getenv' not in und, [ln for ln in und.splitlines() if 'getenv' in ln]
+    syms = subprocess.run(['nm', '-C', str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert 'qkv_attn_kernel' not in syms and 'attn_out_kernel' not in syms
+    lab = subprocess.run(['nm', '-C', str(_lib.LAB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert 'qkv_attn_kernel' in lab and 'attn_out_kernel' in lab
+    for src in (ROOT / 'oadp_amd' / 'csrc').glob('*'):
+        if src.is_file():
+            assert 'getenv' not in src.read_text(), src
+
+
+def test_pass_config_maps_the_environment_onto_the_config():
+    from oadp_amd.clip.model import _pass_config
+    assert _pass_config(512, {}) == (512, 0)                           # the library's default: 25 600 rows
+    assert _pass_config(512, {'OAKE_PASS_ROWS': '0'}) == (512, -1)     # no row cap
+    assert _pass_config(512, {'OAKE_PASS_ROWS': '29800'}) == (512, 29800)
+    assert _pass_config(512, {'OAKE_PASS_CROPS': '120'}) == (120, -1)  # the cap in crops, no row cap beside it
+    assert _pass_config(64, {'OAKE_PASS_CROPS': '120'}) == (64, -1)

@@ -324,7 +324,7 @@ def test_pass_cap_and_equal_passes_are_invisible(cuda):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
-def test_encode_image_fused_qkv_attention(cuda, dtype, tol):
+def test_encode_image_fused_qkv_attention(cuda, lab, dtype, tol):
     """ln_1 + in_proj + attention as one kernel per layer (csrc/qkv_attn.hip, OAKE_OPT_FUSE_QKV_ATTN) on the full
     ViT-B/32: against the oracle, against the two-launch form (the same 16-bit q / k / v values: the features agree to
     the rounding of different summation orders), that it really is the path taken (profile slot names), and that an
@@ -332,7 +332,13 @@ def test_encode_image_fused_qkv_attention(cuda, dtype, tol):
     form at L = 50 (csrc/qkv_attn_obj.hip's QUAD form), value 2 the three-image one: switching re-permutes the folded
     in-projection (the forms read it in different column orders)."""
     sd = synthetic_state_dict()
-    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48)
+    # (the lab build: value 2's three-image kernel is not in the production library, which must refuse the value)
+    prod, _ = clip.load(sd, compute_dtype=dtype, max_batch=4)
+    prod.encode_image(synthetic_images(2, seed=1).to(cuda))
+    with pytest.raises(Exception, match='lab'):
+        prod.visual.set_option('fuse_qkv_attn', 2)
+    prod.visual.close()
+    model, _ = clip.load(sd, compute_dtype=dtype, max_batch=48, lib=lab)
     x = synthetic_images(46, seed=146)  # 46 = 15 groups of three + one: a ragged last tile
     ref = l2_normalize(encode_image_ref(sd, ViTConfig(), x))
     v = model.visual

@@ -184,7 +184,7 @@ def _attention_ref(qkv, n, l, heads):
 @pytest.mark.parametrize('n,l,heads', [(3, 50, 12), (1, 50, 12), (2, 50, 12), (256, 50, 12), (7, 50, 3), (100, 50, 12),
                                        (5, 53, 4), (4, 17, 3), (3, 1, 3), (9, 33, 12), (770, 50, 12), (5, 49, 4),
                                        (1030, 50, 12), (6, 48, 3)])
-def test_ln_qkv_attention_fused(lib, cuda, dtype, n, l, heads, form):
+def test_ln_qkv_attention_fused(lib, lab, cuda, dtype, n, l, heads, form):
     """csrc/qkv_attn.hip: ln_1 folded into attn.in_proj + softmax(q k^T) v as ONE persistent kernel (a tile = three
     images x one head; q | k | v go from the accumulators through LDS into the attention) against the same chain in
     fp32 torch from the same 16-bit x: LayerNorm -> in_proj -> ROUNDED to 16 bits (as the two-launch form stores it) ->
@@ -194,7 +194,8 @@ def test_ln_qkv_attention_fused(lib, cuda, dtype, n, l, heads, form):
     images' rows start at odd LDS rows; 1030 images: a last group of two)."""
     if form == 'quad' and l > 50:
         pytest.skip('four images of more than 50 tokens do not fit the 208-row tile')
-    entry = lib.oake_debug_ln_qkv_attn_quad if form == 'quad' else lib.oake_debug_ln_qkv_attn
+    # (the three-image form lost its A/B and is in the lab build only; the production library answers UNSUPPORTED)
+    entry = lib.oake_debug_ln_qkv_attn_quad if form == 'quad' else lab.oake_debug_ln_qkv_attn
     c = heads * 64
     g = torch.Generator(device='cpu').manual_seed(n * 1000 + l * 10 + heads)
     x = torch.randn(n * l, c, generator=g) * 1.5 + 0.3
@@ -289,14 +290,59 @@ def test_ln_qkv_attention_objects_fused(lib, cuda, dtype, mask_dtype, n, l, head
     assert torch.equal(out[m:], torch.full((3, c), 7.0, dtype=dtype, device=cuda))
 
 
-def test_ln_qkv_attention_refuses_long_sequences(lib, cuda):
+def test_ln_qkv_attention_refuses_long_sequences(lib, lab, cuda):
     z = torch.zeros(64, device=cuda)
     for bad_l in (191, 200, 207, 50):  # objects form: 192 <= l <= 199 only
         assert lib.oake_debug_ln_qkv_attn_obj(*([z.data_ptr()] * 6), _lib.OAKE_F16, z.data_ptr(), 1, bad_l, 12,
                                               _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
     args = [z.data_ptr()] * 6
-    assert lib.oake_debug_ln_qkv_attn(*args, 1, 54, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
-    assert lib.oake_debug_ln_qkv_attn(*args, 1, 197, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lab.oake_debug_ln_qkv_attn(*args, 1, 54, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lab.oake_debug_ln_qkv_attn(*args, 1, 197, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+    # the production library does not carry the three-image form at all
+    assert lib.oake_debug_ln_qkv_attn(*args, 3, 50, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lib.oake_debug_ln_qkv_attn_quad(*args, 1, 51, 12, _lib.OAKE_F16, None, 1, _stream()) == _lib.OAKE_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('walk', [1, 2, 3, 4, 6, 12, 5])
+@pytest.mark.parametrize('form,n,l,heads', [('quad', 256, 50, 12), ('quad', 430, 50, 12), ('quad', 37, 49, 6),
+                                            ('obj', 128, 197, 12), ('obj', 75, 197, 12), ('obj', 9, 193, 6)])
+def test_ln_qkv_attention_tile_walk_is_placement_only(lib, cuda, walk, form, n, l, heads):
+    """OAKE_OPT_QKV_WALK (csrc/qkv_attn_obj.hip::walk_decode): the order in which an XCD's blocks visit the (group, head)
+    tiles — head blocks of `walk` heads x group blocks of 32 / walk groups — is a bijection of the tile set for full and
+    ragged group counts (430 images = 108 groups: XCD ranges cut group blocks; 75 crops; 6 heads: walk 4, 12 and 5 do
+    not divide and fall back to group-major), so every output row is BIT-identical to the group-major walk's."""
+    c = heads * 64
+    m = n * l + (n if form == 'obj' else 0)
+    g = torch.Generator(device='cpu').manual_seed(n * 131 + l + heads)
+    x = (torch.randn(m, c, generator=g) * 1.5 + 0.3).half().to(cuda)
+    w = (torch.randn(3 * c, c, generator=g) * (c ** -0.5)).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(c, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(c, generator=g)).to(cuda)
+    bias = (0.5 * torch.randn(3 * c, generator=g)).to(cuda)
+    mask = (torch.rand(n, l - 1, generator=g) < 0.4).half().to(cuda)
+
+    def run(hq):
+        out = torch.full((m + 3, c), 7.0, dtype=torch.float16, device=cuda)
+        assert lib.oake_debug_set_qkv_walk(hq) == 0
+        try:
+            if form == 'quad':
+                rc = lib.oake_debug_ln_qkv_attn_quad(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     bias.data_ptr(), out.data_ptr(), n, l, heads, _lib.OAKE_F16, None, 1,
+                                                     _stream())
+            else:
+                rc = lib.oake_debug_ln_qkv_attn_obj(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                    bias.data_ptr(), mask.data_ptr(), _lib.OAKE_F16, out.data_ptr(), n, l,
+                                                    heads, _lib.OAKE_F16, None, 1, _stream())
+            assert rc == 0
+            torch.cuda.synchronize()
+        finally:
+            lib.oake_debug_set_qkv_walk(4)
+        return out
+
+    base = run(0)
+    assert torch.isfinite(base[:m].float()).all() and not torch.equal(base[:m], torch.full_like(base[:m], 7.0))
+    assert torch.equal(run(walk), base)
 
 
 # bit 2: K / V shared through LDS for l > 64; bit 4: persistent loader-wave kernel for l <= 64; bit 5 (63):

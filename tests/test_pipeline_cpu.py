@@ -572,6 +572,33 @@ def test_rank_cpus_follow_the_gpus_numa_node(tmp_path, smt):
     assert plan_cpus(2, 8, allowed, None)[0] == list(range(64, 96))
 
 
+def test_rank_cpus_with_one_visible_gpu_per_rank_and_with_fewer_local_shards_than_gpus(tmp_path):
+    """Advisor r05.  (1) HIP_VISIBLE_DEVICES narrowed to ONE GPU per rank (shard_device_index's docstring supports it):
+    a rank sees only its own GPU, so the ranks sharing its NUMA node cannot be counted from the device list — the rank
+    takes 1 / (local_world / #nodes) of the node (here 8 ranks, 2 nodes: a quarter = 32 CPUs), not 1 / local_world of
+    it (16, half of each socket idle).  (2) OAKE_LOCAL_SHARDS=n with n below the GPU count: the device is picked by the
+    GLOBAL shard (r mod #GPUs), so the CPUs must follow THAT GPU's node, not GPU (r mod n)'s."""
+    from oadp_amd.store import _parse_cpulist, pin_cpus, plan_cpus
+    addrs, ncpu = _fake_sysfs(tmp_path, smt='offset')
+    allowed = list(range(ncpu))
+    node = [set(_parse_cpulist((tmp_path / f'devices/system/node/node{n}/cpulist').read_text())) for n in (0, 1)]
+    got = []
+    for r in range(8):  # rank r sees only GPU r
+        keep, how = plan_cpus(r, 8, allowed, [addrs[r]], sysfs=str(tmp_path))
+        assert len(keep) == 32 and set(keep) <= node[r // 4] and 'share' in how, (r, how)
+        got.append(keep)
+    assert sorted(c for k in got for c in k) == allowed  # (ranks of a node contiguous in rank order: disjoint, full cover)
+    # (2) shard 6 of 8 with two local shards: local rank 0, device 6 -> node 1 (GPU 0's node would be node 0)
+    keep, how = plan_cpus(0, 2, allowed, addrs, sysfs=str(tmp_path), device_index=6)
+    assert set(keep) <= node[1] and 'GPU 6' in how, how
+    keep0, _ = plan_cpus(0, 2, allowed, addrs, sysfs=str(tmp_path))
+    assert set(keep0) <= node[0]
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) >= 2:  # pin_cpus hands plan_cpus the device of shard_device_index (no sysfs for these addresses: slices)
+        assert pin_cpus({'OAKE_SHARD': '6/8', 'OAKE_LOCAL_SHARDS': '2'}, gpu_pci=['ffff:ff:1f.0'] * 8, apply=False,
+                        sysfs=str(tmp_path / 'nowhere')) == mine[:len(mine) // 2]
+
+
 def test_pinning_only_where_the_local_rank_count_is_known():
     """Advisor r04 (medium): a lone OAKE_SHARD=0/8 process, a one-process-per-node array job or a launcher that exports
     only the global WORLD_SIZE must NOT be sliced to 1/W of the host."""

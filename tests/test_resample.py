@@ -62,3 +62,18 @@ def test_pass_order_of_very_narrow_sources():
         img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
         ref = np.asarray(PIL.Image.fromarray(img).resize((ow, oh), PIL.Image.BICUBIC))
         assert np.array_equal(resample_ref.resize_ref(img, ow, oh), ref), (w, h, ow, oh)
+
+
+def test_fixed_point_coefficients_fit_the_24_bit_multiply():
+    """Advisor r05: the device resampler multiplies pixel x coefficient with 24-bit integer multiplies
+    (csrc/resample.hip::tap).  Pillow's normalised bicubic weights EXCEED 1 where a window is cut at an image border
+    (the negative lobe of one side is clipped away), so the bound the kernel relies on is |k| < 2^23, not |w| <= 1 —
+    checked here over up- and down-scaling windows incl. every border window, on the oracle's coefficients (pinned
+    bit-exactly to Pillow above; the kernel computes the same integers and clamps at the bound)."""
+    from oracle.resample_ref import PRECISION_BITS, coeffs
+    worst = 0
+    for in_size, out_size in [(7, 224), (32, 224), (224, 224 * 3), (640, 224), (1700, 224), (3, 2), (2, 3), (1, 224),
+                              (5, 4), (500, 499), (33, 224), (480, 320), (1134, 756), (13, 5)]:
+        _, kk = coeffs(in_size, out_size)
+        worst = max(worst, int(np.abs(kk).max()))
+    assert (1 << PRECISION_BITS) < worst < (1 << 23), worst  # above 1.0 at a clipped border, far inside 24 signed bits

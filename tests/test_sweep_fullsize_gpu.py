@@ -19,10 +19,12 @@ encoder) -> L2-normalise:
     per file (blocks), 4 seeded rows per file (objects; the oracle's dual-stream encoder runs ~10 crops/s).
 """
 import json
+import os
 import pathlib
 import shutil
 import subprocess
 import sys
+import time
 
 import numpy as np
 import PIL.Image
@@ -58,8 +60,15 @@ def _close(got: torch.Tensor, ref: torch.Tensor, what: str) -> None:
     torch.testing.assert_close(got, ref, rtol=1e-3, atol=1.25e-3)
 
 
+# Which files and which rows the oracle checks differs from run to run (a fixed choice could
+# hide a defect that hits only, say, proposals clipped at the right image border for ever): OAKE_TEST_SEED names the base
+# seed, default = derived from the clock; it is printed, so a failing draw can be replayed.
+_SEED = int(os.environ['OAKE_TEST_SEED']) if os.environ.get('OAKE_TEST_SEED') else int(time.time()) % 1_000_000
+print(f'[test_sweep_fullsize_gpu] sample seed OAKE_TEST_SEED={_SEED}', flush=True)
+
+
 def _pick(owned: list[int], seed: int) -> list[int]:
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(_SEED * 100 + seed)
     return sorted(int(i) for i in rng.choice(owned, size=N_FILES, replace=False))
 
 
@@ -90,7 +99,7 @@ def test_rank0_share_globals_blocks_at_size(cuda, tmp_path, vit_b32):
         _close(torch.stack(got), l2_normalize(encode_image_ref(vit_b32, cfg, torch.stack(crops))), 'globals')
         # ---- blocks: bboxes of every row bit-exact; block 0 + 3 seeded rows per file against the oracle
         ids = _pick(owned, seed=12)
-        rng = np.random.default_rng(13)
+        rng = np.random.default_rng(_SEED * 100 + 13)
         crops, got = [], []
         for i in ids:
             pil = PIL.Image.open(root / 'train2017' / f'{i:012d}.jpg').convert('RGB')
@@ -129,7 +138,7 @@ def test_rank0_share_objects_at_size(cuda, tmp_path, vit_b32):
         assert modes['objects']['rc'] == 0 and modes['objects']['files_train'] == 2_000, modes['objects']
         owned = list(range(0, 16_000, 8))
         ids = _pick(owned, seed=21)
-        rng = np.random.default_rng(22)
+        rng = np.random.default_rng(_SEED * 100 + 22)
         sd = dict(vit_b32)  # the reference's surgery: positional embedding on the 14 x 14 grid, stride 16, padding 15
         holder = type('P', (), {'positional_embedding': sd['visual.positional_embedding']})()
         sd['visual.positional_embedding'] = VisionTransformer.interpolate_positional_embedding(holder, (14, 14))
