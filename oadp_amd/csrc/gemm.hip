@@ -146,6 +146,12 @@ struct TileMap {
 #ifndef OAKE_KLOOP_ABLATE
 #define OAKE_KLOOP_ABLATE 0
 #endif
+// c_fc (EPI_T16_GELU_LN) on the persistent kernel: 0 = two long phases per K-tile, the whole epilogue at the tile end;
+// 1 = four phases, the tile packed as 16-bit PRE-activations and its QuickGELU + stores deferred into the load phases of
+// the next tile's K loop (gemm_pp_kernel<..., DG = true>; lab variant 12 in either build).  A/B: profiles/r06.
+#ifndef OAKE_DEFER_GELU
+#define OAKE_DEFER_GELU 0
+#endif
 template <typename V>
 __device__ __forceinline__ V resid_load16(const V* p) {
 #if OAKE_RESID_NT
@@ -502,7 +508,12 @@ __device__ __forceinline__ void tile_epilogue_impl(f32x4 (&acc)[MI][NI], int mba
 // store per K-tile of the NEXT tile: all blocks reach their tile ends together, so storing at once
 // is a chip-wide write burst (20 MB at ~5.7 TB/s = 3.5 us with every compute wave stalled in store
 // issue); trickled, the same bytes ride under the next tile's MFMAs at ~2 TB/s.
-template <typename T, int EPI, int MI, int NI, int MI0>
+// DG ("deferred GELU", c_fc): the pending rows are packed as PRE-activations — the LayerNorm affine rounded to 16 bits,
+// which is what the reference's fp16 Linear hands its QuickGELU [REF oadp/oake/globals.py:57 -> clip's ResidualAttentionBlock
+// .mlp: c_fc -> QuickGELU on the fp16 tensor] — and the activation itself is applied piece by piece in the load phases
+// of the NEXT tile's K loop (gelu_piece_half below), where a compute wave otherwise waits at the barrier for its
+// partner's MFMA phase; the rows stored at the tile end (mi < MI0) get it here.
+template <typename T, int EPI, int MI, int NI, int MI0, bool DG = false>
 __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&pend)[MI - MI0][NI / 2],
                                                  const EpiParams& ep, T* row0_ptr, const char* elds,
                                                  int lcol, int lrow) {
@@ -536,7 +547,17 @@ __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&p
         hi[0] = epi_affine<LN>(hi[0], b1.x, ch.x, r); hi[1] = epi_affine<LN>(hi[1], b1.y, ch.y, r);
         hi[2] = epi_affine<LN>(hi[2], b1.z, ch.z, r); hi[3] = epi_affine<LN>(hi[3], b1.w, ch.w, r);
       }
-      if (EpiTraits<EPI>::kGelu) {
+      if (EpiTraits<EPI>::kGelu && (!DG || mi < MI0)) {
+        if constexpr (DG) {  // (the same two roundings as the deferred rows: pre-activation to 16 bits, then the activation)
+          const uint2 q0 = pack4<T>(lo[0], lo[1], lo[2], lo[3]), q1 = pack4<T>(hi[0], hi[1], hi[2], hi[3]);
+          const typename T16<T>::vec4 v0 = __builtin_bit_cast(typename T16<T>::vec4, q0),
+                                      v1 = __builtin_bit_cast(typename T16<T>::vec4, q1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            lo[r] = to32<T>(v0[r]);
+            hi[r] = to32<T>(v1[r]);
+          }
+        }
         quick_gelu4(lo);
         quick_gelu4(hi);
       }
@@ -562,6 +583,17 @@ __device__ __forceinline__ void tile_pack_paired(f32x4 (&acc)[MI][NI], uint4 (&p
     pend[mi - MI0][1] = make_uint4(sb[0], sb[1], sb[2], sb[3]);
   }
 #endif
+}
+
+// QuickGELU of four packed 16-bit values (two registers of a pending piece), in place: unpack -> fp32 quick_gelu4 -> round
+template <typename T>
+__device__ __forceinline__ void gelu_packed4(unsigned& r0, unsigned& r1) {
+  const typename T16<T>::vec4 v = __builtin_bit_cast(typename T16<T>::vec4, make_uint2(r0, r1));
+  f32x4 f = f32x4{to32<T>(v[0]), to32<T>(v[1]), to32<T>(v[2]), to32<T>(v[3])};
+  quick_gelu4(f);
+  const uint2 q = pack4<T>(f[0], f[1], f[2], f[3]);
+  r0 = q.x;
+  r1 = q.y;
 }
 
 template <typename T, int EPI, int MI, int NI>
@@ -841,7 +873,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_deep_kernel(const T* __restr
 //     straight across tile boundaries, so there is no per-tile prologue and the epilogue's stores
 //     drain under the next tile's MFMAs.
 // Measured: 1520 cycles per K-tile in the loop = 84 % MFMA utilisation.
-template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false, bool A32 = false>
+template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false, bool A32 = false, bool DG = false>
 __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __restrict__ A,
                                                                      const T* __restrict__ W, int M,
                                                                      int N, int K, EpiParams ep,
@@ -1214,9 +1246,10 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 #define OAKE_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
   // pending (packed, not yet stored) 16-bit tile: see tile_pack_paired
-  constexpr int MI0 = 1;  // rows stored immediately at tile end: the K-loop holds acc + fragments +
+  constexpr int MI0 = DG ? 2 : 1;  // rows stored immediately at tile end: the K-loop holds acc + fragments +
                           // (MI - MI0) * NI/2 * 4 pending registers inside 168 VGPRs (3 waves per SIMD)
   constexpr bool TRICKLE = EpiTraits<EPI>::kTrickle && !PH2;  // (long phases: the second fragment set takes the pending tile's registers)
+  static_assert(!DG || (TRICKLE && EpiTraits<EPI>::kGelu), "deferred GELU rides on the trickled pieces of a GELU epilogue");
   constexpr int NPEND = TRICKLE ? (MI - MI0) * (NI / 2) : 1;
   uint4 pend[TRICKLE ? MI - MI0 : 1][TRICKLE ? NI / 2 : 1];
   T* pend_ptr = nullptr;  // lane's address of the tile's first row-block (mi = 0, t = 0)
@@ -1266,11 +1299,23 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       OAKE_PRIO(0);
     } else {
     OAKE_LOAD_FRAGS(c_buf, koff0);
+    if constexpr (DG) if (pend_next < NPEND) {
+      // deferred GELU: the first half of this K-tile's piece, under the fragment reads just issued (the wave would
+      // otherwise wait for them and then at the barrier for its partner's MFMA phase)
+#pragma unroll
+      for (int i = 0; i < NPEND; ++i)
+        if (i == pend_next) gelu_packed4<T>(pend[i / (NI / 2)][i % (NI / 2)].x, pend[i / (NI / 2)][i % (NI / 2)].y);
+    }
     OAKE_LGKM0();
     OAKE_BAR();
     OAKE_MFMA_BLOCK();
     OAKE_BAR();
     OAKE_LOAD_FRAGS(c_buf, koff1);
+    if constexpr (DG) if (pend_next < NPEND) {
+#pragma unroll
+      for (int i = 0; i < NPEND; ++i)
+        if (i == pend_next) gelu_packed4<T>(pend[i / (NI / 2)][i % (NI / 2)].z, pend[i / (NI / 2)][i % (NI / 2)].w);
+    }
     OAKE_LGKM0();
     if constexpr (TRICKLE) if (pend_next < NPEND) {
       // one trickled store per K-tile, in this wave's load phase (static register indices: a
@@ -1311,13 +1356,19 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
           // flush what is still pending from the previous tile (only when a tile has < NPEND K-tiles)
 #pragma unroll
           for (int i = 0; i < NPEND; ++i)
-            if (i >= pend_next) OAKE_STORE_PEND(i);
+            if (i >= pend_next) {
+              if constexpr (DG) {
+                gelu_packed4<T>(pend[i / (NI / 2)][i % (NI / 2)].x, pend[i / (NI / 2)][i % (NI / 2)].y);
+                gelu_packed4<T>(pend[i / (NI / 2)][i % (NI / 2)].z, pend[i / (NI / 2)][i % (NI / 2)].w);
+              }
+              OAKE_STORE_PEND(i);
+            }
           pend_next = NPEND;
           if (interior) {
             pend_ptr = reinterpret_cast<T*>(ep.out) + (size_t)(m0 + wm * TM + frow) * ep.ldo + n0 +
                        wn * TN + 8 * fg;
-            tile_pack_paired<T, EPI, MI, NI, MI0>(acc, pend, ep, pend_ptr, elds, wn * TN + 8 * fg,
-                                                  wm * TM + frow);
+            tile_pack_paired<T, EPI, MI, NI, MI0, DG>(acc, pend, ep, pend_ptr, elds, wn * TN + 8 * fg,
+                                                      wm * TM + frow);
 #if OAKE_TRICKLE_FULLLINE
             pend_ptr += (ptrdiff_t)((frow & 7) - frow) * ep.ldo + ((frow & 8) ? 32 : 0);
 #endif
@@ -1350,7 +1401,13 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
   if constexpr (TRICKLE) {
 #pragma unroll
     for (int i = 0; i < NPEND; ++i)
-      if (i >= pend_next) OAKE_STORE_PEND(i);
+      if (i >= pend_next) {
+        if constexpr (DG) {
+          gelu_packed4<T>(pend[i / (NI / 2)][i % (NI / 2)].x, pend[i / (NI / 2)][i % (NI / 2)].y);
+          gelu_packed4<T>(pend[i / (NI / 2)][i % (NI / 2)].z, pend[i / (NI / 2)][i % (NI / 2)].w);
+        }
+        OAKE_STORE_PEND(i);
+      }
   }
   {
     int m0, n0;
@@ -1492,12 +1549,12 @@ hipError_t launch_q4(const GemmArgs& a, hipStream_t s) {
 
 #endif
 
-template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false, bool A32 = false>
+template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PH2 = false, bool A32 = false, bool DG = false>
 hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * kRowBytes + EpiLds::kBytes;
   static_assert(BM <= 160 && BN <= 256, "EpiLds layout");
   static DynLdsAttr attr;
-  auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN, PH2, A32>;
+  auto kern = gemm_pp_kernel<T, EPI, BM, BN, WM, WN, PH2, A32, DG>;
   if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   int num_cu = 0;
   if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
@@ -1572,6 +1629,7 @@ hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
 //                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
 //                  7: one compute wave per SIMD, 160x256, one tile per block (gemm_q4_kernel; experiment)
 //                 11: two workgroups per CU, 160x128 tiles (gemm_duo_kernel; experiment)
+//                 12: variant 4 with c_fc's QuickGELU deferred into the next tile's load phases (four phases; OAKE_DEFER_GELU)
 #if OAKE_LAB
 template <typename T, int EPI>
 hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
@@ -1598,7 +1656,8 @@ hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
       // beat four phases + trickled stores there (+1.1 % on the bench, A/B of two builds in one session; for
       // qkv's lighter epilogue the same switch is neutral: it keeps the trickled stores)
       else if constexpr (EPI == EPI_T16_GELU_LN)
-        return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
+        return OAKE_DEFER_GELU ? launch_pp<T, EPI, 160, 256, 2, 4, false, false, true>(a, s)
+                               : launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
       // ... and, with the tile stores written through (round 3), for qkv's too: all of a tile's stores at its end
       // as full lines, nothing left dirty in the L2s — +0.7 % globals, +0.4 % blocks, +0.2 % objects
       // (profiles/r03/ab_session_k_*; before the write-through stores the same switch was neutral)
@@ -1612,6 +1671,11 @@ hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
       else
         return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     case 10: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);  // four short phases for every epilogue (A/B, cycle stamps)
+    case 12:  // four phases + the QuickGELU of c_fc deferred into the next tile's load phases (round 6)
+      if constexpr (EPI == EPI_T16_GELU_LN || EPI == EPI_T16_GELU)
+        return launch_pp<T, EPI, 160, 256, 2, 4, false, false, true>(a, s);
+      else
+        return launch_variant_lab<T, EPI>(4, a, s);
     case 5: return launch_deep<T, EPI, 64, 64, 2, 2>(a, s);
     case 6: return launch_simple<T, EPI, 64, 64, 2, 2>(a, s);
     case 8: return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);  // experiment: 64 x 64 wave tiles
@@ -1646,6 +1710,9 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
     case 4:  // two long phases per K-tile where the epilogue keeps no tile pending (residual, conv1) and for the
              // LayerNorm-folded epilogues (qkv, c_fc: all of a tile's stores at its end, full lines, written through)
       if (a.patch_f32) return hipErrorInvalidValue;  // (fp32 conv1 gather through the DMA waves' registers: lab build)
+#if OAKE_DEFER_GELU
+      if constexpr (EPI == EPI_T16_GELU_LN) return launch_pp<T, EPI, 160, 256, 2, 4, false, false, true>(a, s);
+#endif
       if constexpr (EPI == EPI_RESID16 || EPI == EPI_PATCH16 || EPI == EPI_T16_GELU_LN || EPI == EPI_T16_BIAS_LN)
         return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
       else
@@ -1687,7 +1754,7 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 
 bool gemm_variant_supported(int v) {
 #if OAKE_LAB
-  return v >= -1 && v <= 11;
+  return v >= -1 && v <= 12;
 #else
   return v == -1 || v == 0 || v == 4 || v == 5;
 #endif
@@ -1698,7 +1765,7 @@ bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts) {
   a.M = M; a.N = N; a.K = K;
   a.opts = opts;
   const int v = pick_variant(a);
-  return (v == 4 || v == 8 || v == 9 || v == 10 || v == 11) && K >= 3 * BK;
+  return (v == 4 || v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && K >= 3 * BK;
 }
 
 bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,

@@ -49,7 +49,9 @@ constexpr int kLStage = (LBM + LBN) * kRowBytes;  // 51 200
 constexpr int kLNStage = 3;
 constexpr int kLEpi = kLNStage * kLStage;         // 153 600: bias[192] | colsum[192] | rowstat[208] | key bias[208]
 constexpr int kLBias = kLEpi, kLColsum = kLEpi + 1024, kLRowstat = kLEpi + 2048, kLMbias = kLEpi + 2048 + LBM * 8;
-constexpr int kLLdsBytes = kLMbias + LBM * 4;     // 158 144 (the key bias is 16-bit: half of its slot)
+constexpr int kLWalkTab = kLMbias + LBM * 4;      // 158 144 (the key bias is 16-bit: half of its slot)
+constexpr int kLWalkN = 256;                      // this block's first 256 tiles, decoded once at entry: (group << 8) | head
+constexpr int kLLdsBytes = kLWalkTab + kLWalkN * 4;  // 159 168
 constexpr int kLNKT = 13;                         // key / query tiles of 16
 constexpr int kRowParts = 16;
 constexpr float kLog2e = 1.4426950408889634f;
@@ -535,8 +537,17 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
     QO_BAR();  // X4: v is in LDS (over the q region)
     if (stamp) QO_STAMP(LATE ? 1 : 0, ti, 6);
     {
+      // (group, head) of the tile: decoded once per block at entry into an LDS table (three runtime divisions per
+      // decode: ~400 cycles in front of every wave's output stores otherwise — what made the blocked walk LOSE 0.6-1 %
+      // although it halves the kernel's fabric reads, profiles/r06/ab_qkv_walk_*.log)
       int img, head;
-      walk_decode(xb + xslot + ti * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, img, head);
+      if (ti < kLWalkN) {
+        const int pk = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + kLWalkTab + ti * 4));
+        img = pk >> 8;
+        head = pk & 255;
+      } else {
+        walk_decode(xb + xslot + ti * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, img, head);
+      }
       if constexpr (QUAD) {
         const int row_first = img * 4 * L;  // (img: the tile's group of four images)
         quad_task_pv<T, 1>(qtask, qs, wid, L, reinterpret_cast<char*>(out + (size_t)row_first * C + head * kHeadDim),
@@ -581,6 +592,14 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
   if (my_tiles == 0) return;
   const int nk = K / BK;
   const int total = my_tiles * nk;
+  if (wid == 0) {  // this block's tile list, decoded by the lanes of one wave (visible to every wave behind barrier B0)
+    for (int i = lane; i < (my_tiles < kLWalkN ? my_tiles : kLWalkN); i += 64) {
+      int g_, h_;
+      walk_decode(xb + xslot + i * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, g_, h_);
+      *reinterpret_cast<int*>(smem + kLWalkTab + i * 4) = (g_ << 8) | h_;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the table is written before this wave arrives at B0
+  }
 
   if (wid >= NW) {
     // ================= DMA wave =================
@@ -598,9 +617,14 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
       }
       return rr < L ? img * L + rr : p.T + img;
     };
+    // (group, head) of the tile being staged and of its predecessor — the consumer position is at most one tile behind the
+    // producer cursor — so the decode (three runtime divisions) runs once per tile in this wave, not five times
+    int dec_tile = -1, dec_img = 0, dec_head = 0, prev_img = 0, prev_head = 0;
     auto set_src = [&](int tile_i) {
       int img, head;
       walk_decode(xb + xslot + tile_i * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, img, head);
+      prev_img = dec_img; prev_head = dec_head;
+      dec_tile = tile_i; dec_img = img; dec_head = head;
 #pragma unroll
       for (int j = 0; j < NPLMAX; ++j) {
         int ii = lw + NL * j;
@@ -653,8 +677,9 @@ __global__ __launch_bounds__(768) void qkv_attn_obj_kernel(const T* __restrict__
     QO_BAR();  // B0
     constexpr int RPW = LBM / NL;  // 52 rows per DMA wave, one per lane
     float st_rstd = 0.f, st_shift = 0.f;
-    auto tile_of = [&](int tile_i, int& img, int& head) {
-      walk_decode(xb + xslot + tile_i * per_xcd, QUAD ? (p.n_img + 3) / 4 : p.n_img, H, p.walk_hq, p.walk_gq, img, head);
+    auto tile_of = [&](int tile_i, int& img, int& head) {  // tile_i = dec_tile or dec_tile - 1 (set_src has run for both)
+      img = tile_i == dec_tile ? dec_img : prev_img;
+      head = tile_i == dec_tile ? dec_head : prev_head;
     };
     for (int g = 0; g < total; ++g) {
       if (d_kt == 0 && lane < RPW) {

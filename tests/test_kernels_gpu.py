@@ -40,11 +40,11 @@ def test_gemm_tile_configs(lib, lab, cuda, variant, m, n, k):
         lib.oake_debug_set_gemm_variant(-1)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize('gelu', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 136, 512),
-                                   (12800, 3072, 128)])
+                                   (12800, 3072, 128), (12800, 3072, 768), (12800, 2048, 192)])
 def test_gemm_16bit_epilogues(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     """QKV / c_fc epilogues: bias (+QuickGELU) and the paired-column 16-byte stores."""
     lib = lib if variant in PROD_GEMM else lab
@@ -68,11 +68,11 @@ def test_gemm_16bit_epilogues(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 4, 5, 6, 8])
+@pytest.mark.parametrize('variant', [0, 1, 4, 5, 6, 8, 12])
 @pytest.mark.parametrize('gelu', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (50, 2304, 768), (333, 136, 512),
-                                   (12800, 1024, 256)])
+                                   (12800, 1024, 256), (12800, 3072, 768), (25600, 1536, 192)])
 def test_gemm_layernorm_folded(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     """LayerNorm folded into the consuming GEMM (16-bit residual stream): gamma in W, beta in the
     bias, per-row (rstd, -mean*rstd) applied in the epilogue == GEMM(LayerNorm(x)) in fp32."""
@@ -497,11 +497,11 @@ def test_production_library_refuses_lab_variants(lib, lab):
     """the product carries only what its own selection can return; the experiments are in the
     lab build, and both say which they are."""
     assert lib.oake_debug_lab_build() == 0 and lab.oake_debug_lab_build() == 1
-    for v in range(-1, 12):
+    for v in range(-1, 13):
         want = _lib.OAKE_OK if v in PROD_GEMM else _lib.OAKE_ERR_UNSUPPORTED
         assert lib.oake_debug_set_gemm_variant(v) == want, v
         assert lab.oake_debug_set_gemm_variant(v) == _lib.OAKE_OK
-    assert lib.oake_debug_set_gemm_variant(12) == lab.oake_debug_set_gemm_variant(12) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lib.oake_debug_set_gemm_variant(13) == lab.oake_debug_set_gemm_variant(13) == _lib.OAKE_ERR_UNSUPPORTED
     lib.oake_debug_set_gemm_variant(-1)
     lab.oake_debug_set_gemm_variant(-1)
     for v in (0, 7, 30, 63, 95, 128, 191, 255, 256, -1):
