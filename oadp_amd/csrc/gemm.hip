@@ -142,7 +142,10 @@ struct TileMap {
 // Measurement builds of the persistent kernel's K loop (WRONG results; tools/kloop_ablate.sh, profiles/r06/kloop_ablation.md):
 // which resource a K-tile's time follows.  Bits: 1 = half of the fragment reads (the odd fragments are copies of the even
 // ones: 5 of 9 ds_read_b128 per kk), 2 = half of the LDS-DMA pieces (the odd pieces of a DMA wave are never issued: 7 of
-// 13), 4 = half of the MFMAs (the odd column tiles are skipped).  Barriers, waits and phases are unchanged in every form.
+// 13), 4 = half of the MFMAs (the odd column tiles are skipped), 8 = every LDS-DMA piece issued, but the odd pieces fetch
+// the SAME source lines as their even neighbour (full request / LDS-write traffic, half of the distinct bytes: separates
+// what the dropped pieces of form 2 save in data movement from what the stale operands save in MFMA operand toggling).
+// Barriers, waits and phases are unchanged in every form.
 #ifndef OAKE_KLOOP_ABLATE
 #define OAKE_KLOOP_ABLATE 0
 #endif
@@ -1034,6 +1037,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       ++d_tile;                                                                                 \
     }                                                                                           \
   } while (0)
+// (form 8: piece j reads what piece j & ~1 reads — never across the A / W boundary: kAPieces = 5 is odd, piece 4 | 5 differ)
+#define OAKE_ABL_SRC(j_) (((OAKE_KLOOP_ABLATE & 8) && ((j_) & 1) && (((j_) - 1 < kAPieces) == ((j_) < kAPieces))) ? (j_) - 1 : (j_))
 #define OAKE_STAGE(j0_, j1_)                                                                 \
   do {                                                                                       \
     if (s_g < total) {                                                                       \
@@ -1043,11 +1048,11 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       _Pragma("unroll") for (int _j = (j0_); _j < (j1_); ++_j)                               \
           if ((!A32 || _j >= kAPieces) && !((OAKE_KLOOP_ABLATE & 2) && !A32 && (_j & 1))) {  \
             if (_j < kAPieces)                                                               \
-              __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koffa),                \
+              __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[OAKE_ABL_SRC(_j)] + _koffa),  \
                                                (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0,           \
                                                EPI == EPI_RESID16 ? OAKE_GEMM_A_AUX_RESID : OAKE_GEMM_A_AUX); \
             else                                                                             \
-              __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[_j] + _koff),                 \
+              __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[OAKE_ABL_SRC(_j)] + _koff),   \
                                                (lds_ptr_t)(_base + (lw + NL * _j) * 1024), 16, 0, OAKE_GEMM_W_AUX); \
           }                                                                                  \
     }                                                                                        \
@@ -1171,6 +1176,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     }
     OAKE_BAR();  // pairs with compute group 1's last phase
 #undef OAKE_STAGE
+#undef OAKE_ABL_SRC
 #undef OAKE_STAGE_EPI
 #undef OAKE_ADVANCE
 #undef OAKE_VMCNT
