@@ -352,7 +352,7 @@ class ObjectsWork(_Work):
             fg = prop - torch.cat([boxes[:, :2], boxes[:, :2]], dim=1)
             masks.append(ds._masks(fg, boxes))
             boxes_per_image.append(boxes)
-        objs = v.crop_resize_normalize_batch(self.images, boxes_per_image, out_dtype=torch.float16)
+        objs = v.crop_resize_normalize_batch(self.images, boxes_per_image, out_dtype=torch.float16, pool_slot=slot)
         m = torch.cat(masks).half()  # 0/1: exact in fp16; up through a pinned slot, as objects.Validator does
         slot, buf = self.pool.acquire(m.numel(), m.dtype)  # (shadows the lane slot: not used below)
         src = buf.view(m.shape)

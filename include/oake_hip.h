@@ -69,6 +69,12 @@ enum {
   OAKE_BF16 = 2,
   OAKE_U8 = 3
 };
+/* Layout flag, OR-ed into the `out_dtype` of oake_crop_resize_normalize(_batch) and the `in_dtype` of oake_encode_objects on
+ * a handle whose conv1 pads (objects mode: stride 16, padding 15 [REF oadp/oake/objects.py:298-301]): the crops are written
+ * into / read from the ZERO-PADDED 16-bit batch [n, 3, rows, row_stride] conv1 gathers its patches from (oake_padded_layout:
+ * the image at (padding, padding) of each plane) instead of a dense [n,3,S,S] tensor, and the library's own pad pass over
+ * the batch is not run.  The caller creates the buffer zero-filled once; the writer keeps every border element zero. */
+#define OAKE_LAYOUT_PADDED 0x100
 
 typedef struct oake_handle oake_handle;
 
@@ -122,6 +128,10 @@ OAKE_API const char* oake_last_error(const oake_handle* h);
 /* Derived geometry: grid = (image + 2*padding - patch)/stride + 1, tokens = grid*grid + 1. */
 OAKE_API int oake_grid(const oake_handle* h);
 OAKE_API int oake_tokens(const oake_handle* h);
+/* Geometry of the zero-padded 16-bit batch this handle's conv1 gathers its patches from (OAKE_LAYOUT_PADDED): planes of
+ * `rows` x `row_stride` pixels, the image at (padding, padding).  OAKE_ERR_UNSUPPORTED for handles whose conv1 does not
+ * pad / cut patches (encode_image at stride == patch), for fp32 residual streams and text handles. */
+OAKE_API int oake_padded_layout(const oake_handle* h, int* padding, int* rows, int* row_stride);
 
 /*
  * Upload one tensor of the OpenAI-CLIP state_dict by its key (the same keys the reference's
@@ -187,7 +197,9 @@ OAKE_API int oake_crop_resize_normalize(oake_handle* h, const uint8_t* d_image_h
                                void* d_out, int out_dtype, void* stream);
 /* The same for the images of one flush in ONE call (a sweep otherwise pays an interpreter round trip
  * per image): image i (d_images[i], heights[i] x widths[i]) contributes counts[i] boxes, taken in order
- * from h_boxes_xyxy; d_out is [sum counts, 3, out, out], image after image. */
+ * from h_boxes_xyxy; d_out is [sum counts, 3, out, out], image after image — or, with out_dtype = OAKE_F16 |
+ * OAKE_LAYOUT_PADDED, the zero-padded batch [sum counts, 3, rows, row_stride] of oake_padded_layout (out == the handle's
+ * image size; bit-identical pixels, csrc/resample.hip resample_v4p_kernel). */
 OAKE_API int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, const uint8_t* const* d_images,
                                      const int* heights, const int* widths, const float* h_boxes_xyxy,
                                      const int* counts, int out_size, int squash, const float* h_mean3,

@@ -9,6 +9,7 @@ import pathlib
 OAKE_OK = 0
 OAKE_ERR_INVALID, OAKE_ERR_HIP, OAKE_ERR_STATE, OAKE_ERR_UNKNOWN_TENSOR, OAKE_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 OAKE_F32, OAKE_F16, OAKE_BF16, OAKE_U8 = 0, 1, 2, 3
+OAKE_LAYOUT_PADDED = 0x100
 OAKE_OPT_CLS_LAST, OAKE_OPT_GEMM_VARIANT, OAKE_OPT_GEMM_PANEL, OAKE_OPT_ATTENTION_VARIANT = 1, 2, 3, 4
 OAKE_OPT_PATCH_DIRECT = 5
 OAKE_OPT_CU_COUNT = 6
@@ -43,6 +44,7 @@ SIGNATURES = {
     'oake_last_error': (C.c_char_p, [_VP]),
     'oake_grid': (_I, [_VP]),
     'oake_tokens': (_I, [_VP]),
+    'oake_padded_layout': (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     'oake_load_tensor': (_I, [_VP, C.c_char_p, _VP, C.c_size_t]),
     'oake_missing_tensors': (_I, [_VP]),
     'oake_encode_image': (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _VP]),

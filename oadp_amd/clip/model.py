@@ -175,6 +175,12 @@ class VisionTransformer(_HookPoint):
         self.lane = 0
         self._lanes: dict[int, tuple] = {}
         self._options: dict[int, int] = {}  # oake_set_option values, applied to every lane's handle
+        # objects mode: crop_resize_normalize_batch writes its f16 crops straight into the zero-padded batch conv1 gathers
+        # from (OAKE_LAYOUT_PADDED) and hands out a strided [N,3,S,S] VIEW of it; visual(objects, masks) recognises the view
+        # and the library skips its pad pass.  One reusable pool per (lane, pool_slot): a view is valid until the next crop
+        # call on the same lane and slot (the validators and bench.py encode a flush before they crop the next one).
+        self.padded_crops = os.environ.get('OAKE_PADDED_CROPS', '1') not in ('0', 'false', 'False')
+        self._pad_pools: dict[tuple, tuple] = {}
 
     @property
     def _handle(self):
@@ -344,6 +350,7 @@ class VisionTransformer(_HookPoint):
         for h, _ in self._lanes.values():
             self._lib.oake_destroy(h)
         self._lanes.clear()
+        self._pad_pools.clear()
 
     def __del__(self) -> None:  # pragma: no cover
         try:
@@ -368,7 +375,9 @@ class VisionTransformer(_HookPoint):
         else:
             raise TypeError(f'unsupported output dtype {out_dtype}')
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-        x = x.contiguous()
+        padded_base = self._padded_view_base(x) if masks is not None else None
+        if padded_base is None:
+            x = x.contiguous()
         n = x.shape[0]
         out = torch.empty((n, self.output_dim), dtype=raw_dtype, device=x.device)
         with torch.cuda.device(dev):
@@ -386,13 +395,53 @@ class VisionTransformer(_HookPoint):
                 if masks.shape[0] != n or masks.numel() != n * g * g:
                     raise ValueError(f'masks must be [N,1,{g},{g}], got {tuple(masks.shape)}')
                 masks = masks.to(x.device).contiguous()
-                rc = lib.oake_encode_objects(h, x.data_ptr(), _TORCH2OAKE[x.dtype], masks.data_ptr(),
-                                             _TORCH2OAKE[masks.dtype], n, out.data_ptr(),
-                                             _TORCH2OAKE[raw_dtype], int(normalize), stream)
+                if padded_base is not None:  # a view of the zero-padded crop pool: no pad pass in the library
+                    rc = lib.oake_encode_objects(h, padded_base, _TORCH2OAKE[x.dtype] | _lib.OAKE_LAYOUT_PADDED,
+                                                 masks.data_ptr(), _TORCH2OAKE[masks.dtype], n, out.data_ptr(),
+                                                 _TORCH2OAKE[raw_dtype], int(normalize), stream)
+                else:
+                    rc = lib.oake_encode_objects(h, x.data_ptr(), _TORCH2OAKE[x.dtype], masks.data_ptr(),
+                                                 _TORCH2OAKE[masks.dtype], n, out.data_ptr(),
+                                                 _TORCH2OAKE[raw_dtype], int(normalize), stream)
                 _lib.check(lib, h, rc, 'oake_encode_objects')
         return out if out.dtype == out_dtype else out.to(out_dtype)
 
     # -- device-side preprocessing (csrc/resample.hip, rowops.hip) -------------------------------
+    def _padded_layout(self, h) -> tuple[int, int, int] | None:
+        """(padding, rows, row_stride) of the zero-padded batch this handle's conv1 gathers from, or None."""
+        pad, hp, ws = C.c_int(0), C.c_int(0), C.c_int(0)
+        if self._lib.oake_padded_layout(h, C.byref(pad), C.byref(hp), C.byref(ws)) != _lib.OAKE_OK:
+            return None
+        return pad.value, hp.value, ws.value
+
+    def _padded_view_base(self, x: torch.Tensor) -> int | None:
+        """Device address of plane 0 / row 0 of the first crop if `x` is a [k,3,S,S] view of one of this model's padded
+        crop pools (a dim-0 slice of what crop_resize_normalize_batch returned), else None."""
+        if x.is_contiguous() or not self._pad_pools or x.dim() != 4:
+            return None
+        for pool, pad, hp, ws in self._pad_pools.values():
+            plane = hp * ws
+            if (x.dtype == pool.dtype and x.device == pool.device and x.stride() == (3 * plane, plane, ws, 1)
+                    and x.untyped_storage().data_ptr() == pool.untyped_storage().data_ptr()
+                    and x.storage_offset() % (3 * plane) == pad * ws + pad):
+                return x.data_ptr() - (pad * ws + pad) * x.element_size()
+        return None
+
+    def _padded_pool(self, h, k: int, slot: int, device: torch.device):
+        """The zero-filled pool [cap >= k, 3, rows, row_stride] of (lane, slot) for this handle's geometry, or None where the
+        handle takes no padded batch.  Created (and grown) with zeros; the writer keeps every border element zero."""
+        lay = self._padded_layout(h)
+        if lay is None:
+            return None
+        pad, hp, ws = lay
+        key = (self.lane, slot)
+        cur = self._pad_pools.get(key)
+        if cur is None or cur[0].shape[0] < k or cur[1:] != (pad, hp, ws) or cur[0].device != device:
+            cap = max(k, cur[0].shape[0] if cur is not None and cur[1:] == (pad, hp, ws) else 0)
+            cur = (torch.zeros((cap, 3, hp, ws), dtype=torch.float16, device=device), pad, hp, ws)
+            self._pad_pools[key] = cur
+        return cur
+
     def _image_args(self, image_u8: torch.Tensor):
         if not image_u8.is_cuda or image_u8.dtype != torch.uint8 or image_u8.dim() != 3 or image_u8.shape[2] != 3:
             raise ValueError('expected a uint8 HWC RGB tensor on the GPU')
@@ -434,9 +483,14 @@ class VisionTransformer(_HookPoint):
         return out
 
     def crop_resize_normalize_batch(self, images_u8: list[torch.Tensor], boxes: list, *, squash: bool = False,
-                                    out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                                    out_dtype: torch.dtype = torch.float32, pool_slot: int = 0) -> torch.Tensor:
         """``torch.cat([crop_resize_normalize(im, b) for im, b in zip(images_u8, boxes)])`` in one native
-        call: ``boxes[i]`` ([k_i,4] floats) are the crops of ``images_u8[i]``."""
+        call: ``boxes[i]`` ([k_i,4] floats) are the crops of ``images_u8[i]``.
+
+        On an objects-mode model (conv1 with padding) with f16 output the result is a strided VIEW of the zero-padded crop
+        pool of (lane, pool_slot) — same shape, same values, valid until the next call on that lane and slot; pass it (or
+        dim-0 slices of it) to ``visual(objects, masks)`` and the encoder reads the pool in place.  ``.contiguous()`` gives
+        an independent dense copy; ``padded_crops = False`` / OAKE_PADDED_CROPS=0 switches the pool off."""
         from .preprocess import CLIP_MEAN, CLIP_STD
         if len(images_u8) != len(boxes):
             raise ValueError('one box list per image')
@@ -453,7 +507,7 @@ class VisionTransformer(_HookPoint):
         bs = [torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4) for b in boxes]
         counts = [b.shape[0] for b in bs]
         allb = torch.cat(bs).cpu().contiguous()
-        out = torch.empty((sum(counts), 3, n, n), dtype=out_dtype, device=imgs[0].device)
+        total = sum(counts)
         m = len(imgs)
         ptrs = (C.c_void_p * m)(*[im.data_ptr() for im in imgs])
         hs = (C.c_int * m)(*[im.shape[0] for im in imgs])
@@ -461,10 +515,20 @@ class VisionTransformer(_HookPoint):
         cs = (C.c_int * m)(*counts)
         with torch.cuda.device(dev):
             h = self._ensure_handle(dev)
+            pool = None
+            if (self.padded_crops and total > 0 and out_dtype == torch.float16 and self.compute_dtype == torch.float16
+                    and self.residual_dtype == torch.float16):
+                pool = self._padded_pool(h, total, pool_slot, imgs[0].device)
+            if pool is not None:
+                buf, pad, _, _ = pool
+                out, dst, flag = buf[:total, :, pad:pad + n, pad:pad + n], buf.data_ptr(), _lib.OAKE_LAYOUT_PADDED
+            else:
+                out = torch.empty((total, 3, n, n), dtype=out_dtype, device=imgs[0].device)
+                dst, flag = out.data_ptr(), 0
             mean, std = (C.c_float * 3)(*CLIP_MEAN), (C.c_float * 3)(*CLIP_STD)
             rc = self._lib.oake_crop_resize_normalize_batch(
-                h, m, ptrs, hs, ws, C.c_void_p(allb.data_ptr()), cs, n, int(squash), mean, std, out.data_ptr(),
-                _TORCH2OAKE[out_dtype], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                h, m, ptrs, hs, ws, C.c_void_p(allb.data_ptr()), cs, n, int(squash), mean, std, dst,
+                _TORCH2OAKE[out_dtype] | flag, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             _lib.check(self._lib, h, rc, 'oake_crop_resize_normalize_batch')
         return out
 

@@ -118,6 +118,8 @@ struct oake_handle {
   float* rowstat = nullptr;   // [B*L, 2] LayerNorm (rstd, -mean*rstd) of the residual rows
   float* rowpart = nullptr;   // [B*L, 16, 2] (sum, sum^2) slices handed from GEMM to GEMM
   void* zero_mask = nullptr;  // [B, L-1] 16-bit zeros: the CLS rows of the last block mask nothing
+  void* unpad = nullptr;      // dense 16-bit copy of a SMALL padded-layout pass (patch_embed; grown on demand)
+  size_t unpad_cap = 0;
   bool stat_fused = false;    // this pass: statistics via rowpart (else the rowstat kernel)
   int nparts = 0;             // valid slices per row in rowpart (1 after embed, width/64 after a GEMM)
   float* e32 = nullptr;       // [head_rows, embed] fp32 head projection
@@ -341,7 +343,7 @@ void oake_destroy(oake_handle* h) {
   void* ptrs[] = {h->conv_w, h->cls, h->pos, h->lnpre_g, h->lnpre_b, h->lnpost_g, h->lnpost_b,
                   h->proj, h->stage, h->a_patch, h->x, h->xn, h->qkv, h->att, h->hbuf, h->y, h->e32,
                   h->yn, h->rs_jobs, h->rs_coef, h->rs_bounds, h->rs_temp, h->crop_jobs, h->pyr,
-                  h->rowstat, h->rowpart, h->zero_mask, h->jp_coefs, h->jp_planes, h->tok_emb};
+                  h->rowstat, h->rowpart, h->zero_mask, h->unpad, h->jp_coefs, h->jp_planes, h->tok_emb};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& l : h->layers) {
@@ -735,7 +737,21 @@ int ln_stats(oake_handle* h, hipStream_t s, const char* xr, size_t r0, int M, in
   return OAKE_OK;
 }
 
-int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, int nb) {
+// the zero-padded 16-bit batch conv1 gathers its patches from when the convolution pads or its stride cuts patches
+// (objects mode): hp rows of ws pixels per colour plane, the image at (padding, padding)
+bool padded_geometry(const oake_handle* h, int* pad, int* hp, int* ws) {
+  const oake_config& c = h->cfg;
+  if (h->text || (c.stride == c.patch_size && c.padding == 0)) return false;
+  *pad = c.padding;
+  *hp = c.image_size + 2 * c.padding;
+  *ws = (c.image_size + 2 * c.padding + 7) & ~7;
+  return h->patch_direct && h->xdt != DT_F32 && (h->grid - 1) * c.stride + c.patch_size <= *hp &&
+         (size_t)3 * *hp * *ws <= (size_t)h->p2 * h->kpatch && c.image_size % 4 == 0;
+}
+
+// in_padded: `imgs` IS that padded batch already (OAKE_LAYOUT_PADDED: the crops were written into it by
+// oake_crop_resize_normalize_batch) — no pad pass
+int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, int nb, bool in_padded = false) {
   const oake_config& c = h->cfg;
   const int C = c.width, L = h->tokens;
   const size_t in_es = in_dtype == DT_F32 ? 4 : 2;
@@ -747,7 +763,7 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   // preprocessing writes fp16 crops): the conv1 GEMM's DMA waves gather the patch rows straight from the
   // NCHW batch — no im2col pass, no a_patch round trip.  Other inputs (fp32, the other 16-bit type,
   // strides that cut patches: objects mode) go through im2col, which also does the cast.
-  const bool direct = h->patch_direct && in_dtype == h->dt16 && h->xdt != DT_F32 &&
+  const bool direct = !in_padded && h->patch_direct && in_dtype == h->dt16 && h->xdt != DT_F32 &&
                       gemm_patch_direct_ok(c.image_size, c.patch_size, c.stride, c.padding, a.M, a.N, a.K, &h->opts) &&
                       reinterpret_cast<uintptr_t>(imgs) % 16 == 0;
   // ... and where the convolution pads or its stride cuts patches (objects mode: stride 16, padding 15), from a
@@ -768,10 +784,28 @@ int patch_embed(oake_handle* h, hipStream_t s, const void* imgs, int in_dtype, i
   const bool direct32 = !direct && h->patch_direct >= 2 && in_dtype == DT_F32 && h->xdt != DT_F32 &&
                         gemm_patch_f32_ok(c.image_size, c.patch_size, c.stride, c.padding, a.M, a.N, a.K, &h->opts) &&
                         reinterpret_cast<uintptr_t>(imgs) % 16 == 0;
+  if (in_padded && !padded) {
+    // a pass too small for the persistent GEMM (a handful of crops): back to a dense batch (a scratch of its own: no
+    // workspace buffer is large enough in every geometry) and the im2col route
+    const size_t need = (size_t)nb * 3 * c.image_size * c.image_size * 2;
+    if (need > h->unpad_cap) {
+      HIP_TRY(h, hipStreamSynchronize(s));
+      if (h->unpad) HIP_TRY(h, hipFree(h->unpad));
+      h->unpad = nullptr; h->unpad_cap = 0;
+      HIP_TRY(h, hipMalloc(&h->unpad, need));
+      h->unpad_cap = need;
+    }
+    RUN(h, s, "unpad_nchw", 0.0, 2.0 * need,
+        launch_unpad_nchw(imgs, h->unpad, nb, c.image_size, c.padding, hp, ws, s));
+    return patch_embed(h, s, h->unpad, h->dt16, nb, false);
+  }
   if (direct || direct32) {
     a.A = imgs;
     a.patch_S = c.image_size; a.patch_P = c.patch_size; a.patch_G = h->grid;
     a.patch_f32 = direct32 ? 1 : 0;
+  } else if (padded && in_padded) {
+    a.A = imgs;
+    a.patch_S = ws; a.patch_H = hp; a.patch_P = c.patch_size; a.patch_T = c.stride; a.patch_G = h->grid;
   } else if (padded) {
     RUN(h, s, "pad_nchw", 0.0, (double)nb * 3 * hp * ws * 2 + (double)nb * 3 * c.image_size * c.image_size * in_es,
         launch_pad_nchw(h->dt16, imgs, in_dtype, h->a_patch, nb, c.image_size, c.padding, hp, ws, s));
@@ -1046,7 +1080,8 @@ int upload_async(oake_handle* h, hipStream_t s, const void* host, size_t bytes, 
 // jobs (each naming its source image) -> device, scratch sizing, three launches.  The offsets of `jobs`
 // are filled here.  out_dtype DT_U8: every job writes its own image to job.u8_out.
 int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, int out_size,
-                 const float* mean3, const float* std3, void* d_out, int out_dtype) {
+                 const float* mean3, const float* std3, void* d_out, int out_dtype, int out_pad = 0, int out_hp = 0,
+                 int out_ws = 0) {
   if (jobs.empty()) return OAKE_OK;
   long coef = 0, bnd = 0, temp = 0;
   int max_out = 1;
@@ -1062,16 +1097,19 @@ int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, 
     j.coefv_off = coef; coef += (long)j.rh * j.kv;
     j.boundh_off = bnd; bnd += 2L * j.rw;
     j.boundv_off = bnd; bnd += 2L * j.rh;
-    j.temp_off = temp; temp += (long)j.ch * j.rw * 3;
+    j.tstride = 12 * ((j.rw + 3) / 4);  // rows of the intermediate image: whole 12-byte quads of pixels
+    j.temp_off = temp; temp += ((long)j.ch * j.tstride + 15) & ~15L;
     max_out = std::max(max_out, std::max(j.rw, j.rh));
     max_ch_rw = std::max(max_ch_rw, (long)j.ch * j.rw);
-    max_chq_rw = std::max(max_chq_rw, (long)((j.ch + 3) / 4) * j.rw);  // (resample_h_kernel: four rows per thread)
+    max_chq_rw = std::max(max_chq_rw, (long)((j.ch + 3) / 4) * ((j.rw + 3) & ~3));  // (resample_h_kernel: four rows per thread, whole quads)
     max_rh_rw = std::max(max_rh_rw, (long)j.rh * j.rw);
   }
   if (max_ch_rw > 0x7fffffffL || max_rh_rw > 0x7fffffffL) return fail(h, OAKE_ERR_INVALID, "crop too large");
   int rc;
   if ((rc = grow(h, s, &h->rs_jobs, &h->rs_jobs_cap, jobs.size() * sizeof(ResampleJob)))) return rc;
-  if ((rc = grow(h, s, &h->rs_coef, &h->rs_coef_cap, (size_t)coef * 4))) return rc;
+  // (+ 16: the horizontal pass reads a column's coefficients in groups of four and may touch up to three entries past the
+  // last column's row of the table)
+  if ((rc = grow(h, s, &h->rs_coef, &h->rs_coef_cap, (size_t)coef * 4 + 16))) return rc;
   if ((rc = grow(h, s, &h->rs_bounds, &h->rs_bounds_cap, (size_t)bnd * 4))) return rc;
   // (+ 16: resample_v4_kernel's 16-byte loads start at the 4-byte-aligned address below a 12-byte window and may
   // read up to 4 bytes past it — past the last job's temp image when the window is its last 12 bytes)
@@ -1084,7 +1122,7 @@ int run_resample(oake_handle* h, hipStream_t s, std::vector<ResampleJob>& jobs, 
     bytes += (double)jobs.size() * out_size * out_size * 3 * (out_dtype == DT_F32 ? 4 : 2);
   RUN(h, s, "resample", 0.0, bytes,
       launch_resample(h->rs_jobs, (int)jobs.size(), max_out, max_chq_rw, max_rh_rw, h->rs_coef, h->rs_bounds,
-                      h->rs_temp, out_size, mean3, std3, d_out, out_dtype, s));
+                      h->rs_temp, out_size, mean3, std3, d_out, out_dtype, s, out_pad, out_hp, out_ws));
   return OAKE_OK;
 }
 
@@ -1266,8 +1304,15 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
   if (n < 0) return fail(h, OAKE_ERR_INVALID, "negative batch");
   if (n == 0) return OAKE_OK;
   if (!d_objects || !d_masks || !d_out) return fail(h, OAKE_ERR_INVALID, "null device pointer");
+  const bool in_padded = (in_dtype & OAKE_LAYOUT_PADDED) != 0;
+  in_dtype &= ~OAKE_LAYOUT_PADDED;
   if (in_dtype != OAKE_F32 && in_dtype != OAKE_F16 && in_dtype != OAKE_BF16)
     return fail(h, OAKE_ERR_INVALID, "in_dtype must be F32, F16 or BF16");
+  int ppad = 0, php = 0, pws = 0;
+  if (in_padded && (!padded_geometry(h, &ppad, &php, &pws) || in_dtype != h->dt16 ||
+                    reinterpret_cast<uintptr_t>(d_objects) % 16 != 0))
+    return fail(h, OAKE_ERR_INVALID, "OAKE_LAYOUT_PADDED input: the handle's conv1 takes no zero-padded batch (oake_padded_layout), "
+                                     "or the batch is not of the compute type / 16-byte aligned");
   if (mask_dtype != OAKE_F32 && mask_dtype != OAKE_F16)
     return fail(h, OAKE_ERR_INVALID, "mask_dtype must be F32 or F16");
   if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
@@ -1278,7 +1323,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const oake_config& c = h->cfg;
   const int C = c.width, L = h->tokens;
-  const size_t img_bytes = (size_t)3 * c.image_size * c.image_size * dtype_size(in_dtype);
+  const size_t img_bytes = in_padded ? (size_t)3 * php * pws * 2 : (size_t)3 * c.image_size * c.image_size * dtype_size(in_dtype);
   const size_t mask_bytes = (size_t)h->p2 * dtype_size(mask_dtype);
   const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
 
@@ -1292,7 +1337,7 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
     const char* imgs = reinterpret_cast<const char*>(d_objects) + (size_t)b0 * img_bytes;
     const char* masks = reinterpret_cast<const char*>(d_masks) + (size_t)b0 * mask_bytes;
     char* outp = reinterpret_cast<char*>(d_out) + (size_t)b0 * out_bytes;
-    if ((rc = patch_embed(h, s, imgs, in_dtype, nb))) return rc;
+    if ((rc = patch_embed(h, s, imgs, in_dtype, nb, in_padded))) return rc;
     // Hooks.transformer_forward_pre (objects.py:215-221): y = x[[0]] (after ln_pre).  The object
     // tokens live as rows T .. T+nb of the SAME matrices as the patch tokens, so that every layer's
     // GEMMs carry both streams in one launch (they share the weights); only the attention differs.
@@ -1398,8 +1443,15 @@ int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, const uint8_t
   if (n_images == 0) return OAKE_OK;
   if (!d_images || !heights || !widths || !counts || !h_mean3 || !h_std3)
     return fail(h, OAKE_ERR_INVALID, "null pointer");
+  const bool out_padded = (out_dtype & OAKE_LAYOUT_PADDED) != 0;
+  out_dtype &= ~OAKE_LAYOUT_PADDED;
   if (out_dtype != OAKE_F32 && out_dtype != OAKE_F16)
     return fail(h, OAKE_ERR_INVALID, "out_dtype must be F32 or F16");
+  int ppad = 0, php = 0, pws = 0;
+  if (out_padded && (!padded_geometry(h, &ppad, &php, &pws) || out_dtype != h->dt16 || out_dtype != OAKE_F16 ||
+                     out_size != h->cfg.image_size || reinterpret_cast<uintptr_t>(d_out) % 16 != 0))
+    return fail(h, OAKE_ERR_INVALID, "OAKE_LAYOUT_PADDED output: f16 crops of the handle's image size into the zero-padded batch "
+                                     "of a handle whose conv1 pads (oake_padded_layout)");
   size_t total = 0;
   for (int i = 0; i < n_images; ++i) {
     if (counts[i] < 0) return fail(h, OAKE_ERR_INVALID, "negative box count");
@@ -1421,7 +1473,16 @@ int oake_crop_resize_normalize_batch(oake_handle* h, int n_images, const uint8_t
       if (rc != OAKE_OK) return rc;
       jobs[k].out_row = (long)k;
     }
-  return run_resample(h, s, jobs, out_size, h_mean3, h_std3, d_out, out_dtype);
+  return run_resample(h, s, jobs, out_size, h_mean3, h_std3, d_out, out_dtype, out_padded ? ppad : 0, out_padded ? php : 0,
+                      out_padded ? pws : 0);
+}
+
+int oake_padded_layout(const oake_handle* h, int* padding, int* rows, int* row_stride) {
+  if (!h || !padding || !rows || !row_stride) return OAKE_ERR_INVALID;
+  int p = 0, hp = 0, ws = 0;
+  if (!padded_geometry(h, &p, &hp, &ws)) return OAKE_ERR_UNSUPPORTED;
+  *padding = p; *rows = hp; *row_stride = ws;
+  return OAKE_OK;
 }
 
 int oake_resize_u8(oake_handle* h, const uint8_t* d_src_hwc, int sh, int sw, uint8_t* d_dst_hwc,

@@ -134,6 +134,8 @@ hipError_t launch_im2col(int dtype16, const void* img, int in_dtype, void* out, 
 // what the conv1 GEMM gathers its patches from when the convolution pads or its stride cuts patches
 hipError_t launch_pad_nchw(int dtype16, const void* img, int in_dtype, void* out, int n, int image, int pad, int hp,
                            int ws, hipStream_t s);
+// ... and back: the dense 16-bit [n,3,image,image] batch out of the padded one (small passes of a padded-layout call)
+hipError_t launch_unpad_nchw(const void* padded, void* out, int n, int image, int pad, int hp, int ws, hipStream_t s);
 
 // ---- attention ---------------------------------------------------------------------------
 // qkv [n*L, 3*H*64] 16-bit (q pre-scaled by 1/8) -> out [n*L, H*64] 16-bit. Full self-attention.
@@ -223,7 +225,8 @@ struct ResampleJob {
   int kh, kv;          // coefficient taps per output index (horizontal / vertical)
   long coefh_off, coefv_off;    // offsets into the int32 coefficient table
   long boundh_off, boundv_off;  // offsets into the int32 bounds table
-  long temp_off;       // byte offset of this job's horizontal-pass image
+  long temp_off;       // byte offset of this job's horizontal-pass image (16-byte aligned)
+  int tstride;         // bytes between its rows: 12 * ceil(rw / 4) (the horizontal pass stores 12-byte quads)
   long out_row;        // DT_F32 / DT_F16 output: the job's row of `out` [rows,3,out,out]
   uint8_t* u8_out;     // DT_U8 output: this job's rh x rw HWC destination (device)
   // Pass order.  Pillow runs the horizontal pass first — except that a source more than 100 times taller
@@ -235,11 +238,16 @@ struct ResampleJob {
 };
 // out_dtype DT_F32 / DT_F16: normalised crops, job j -> out[j.out_row];
 // DT_U8: every job writes its own uint8 HWC image (rh x rw) to job.u8_out (`out` unused).
-// max_chq_rw / max_rh_rw: the largest ceil(ch / 4) * rw (the horizontal pass: four rows per thread) / rh * rw over
-// the jobs (grid sizing).
+// max_chq_rw / max_rh_rw: the largest ceil(ch / 4) * (rw rounded up to 4) (the horizontal pass: four rows per thread,
+// whole quads of columns) / rh * rw over the jobs (grid sizing).
+// out_ws > 0 (DT_F16, out_size % 4 == 0): job j writes rows out_pad .. out_pad + out_size - 1, columns out_pad .. of its
+// three planes of the zero-padded batch [rows, 3, out_hp, out_ws] conv1 gathers its patches from (objects mode) — the
+// padding columns inside the four-pixel groups it touches are written as zeros, everything else of the border is
+// expected to BE zero already
 hipError_t launch_resample(const ResampleJob* d_jobs, int njobs, int max_out, long max_chq_rw, long max_rh_rw,
                            int32_t* d_coef, int32_t* d_bounds, uint8_t* d_temp, int out_size,
-                           const float* mean3, const float* std3, void* out, int out_dtype, hipStream_t s);
+                           const float* mean3, const float* std3, void* out, int out_dtype, hipStream_t s,
+                           int out_pad = 0, int out_hp = 0, int out_ws = 0);
 
 // Exact-size crops (no resampling) of many images in one launch: job j -> out[j.out_row].
 struct CropJob {

@@ -297,6 +297,19 @@ __global__ __launch_bounds__(256) void pad_nchw_kernel(const TIN* __restrict__ i
   reinterpret_cast<uint4*>(out)[idx] = o;
 }
 
+// the inverse, 16-bit to 16-bit: the dense [n,3,image,image] batch out of the zero-padded one (a pass of a padded-layout
+// call that is too small for the persistent conv1 GEMM and takes the im2col route instead; a handful of crops)
+__global__ __launch_bounds__(256) void unpad_nchw_kernel(const uint16_t* __restrict__ padded, uint16_t* __restrict__ out,
+                                                         long total, int image, int pad, int hp, int ws) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long row = idx / image;  // (n * 3 + c) * image + y
+  const int x = (int)(idx - row * image);
+  const long plane = row / image;
+  const int y = (int)(row - plane * image);
+  out[idx] = padded[((size_t)plane * hp + y + pad) * ws + x + pad];
+}
+
 // ---- text tower glue --------------------------------------------------------------------------
 // token + positional embedding (clip model.py encode_text: token_embedding(text) + positional_embedding)
 template <typename TX>
@@ -654,6 +667,15 @@ hipError_t launch_pad_nchw(int dtype16, const void* img, int in_dtype, void* out
   if (dtype16 == DT_F16) return pad_in<f16_t>(img, in_dtype, out, total8, image, pad, hp, ws, s);
   if (dtype16 == DT_BF16) return pad_in<bf16_t>(img, in_dtype, out, total8, image, pad, hp, ws, s);
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_unpad_nchw(const void* padded, void* out, int n, int image, int pad, int hp, int ws, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (hp < image + pad || ws < image + pad) return hipErrorInvalidValue;
+  const long total = (long)n * 3 * image * image;
+  hipLaunchKernelGGL(unpad_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const uint16_t*>(padded), reinterpret_cast<uint16_t*>(out), total, image, pad, hp, ws);
+  return hipGetLastError();
 }
 
 hipError_t launch_l2norm_rows(const float* in, void* out, int out_dtype, int normalize, int n, int e,

@@ -573,6 +573,94 @@ def test_objects_conv1_from_padded_buffer_equals_im2col(cuda, in_dtype):
     _check(ya[:4], ref, 1e-3, 1e-3)
 
 
+def test_objects_crops_written_into_the_padded_batch(cuda):
+    """objects mode's crops go STRAIGHT into the zero-padded 16-bit batch conv1 gathers from
+    (OAKE_LAYOUT_PADDED: csrc/resample.hip resample_v4p_kernel, `visual.crop_resize_normalize_batch` hands out a strided
+    view of a per-lane pool) and the library's pad pass is not run [REF oadp/oake/objects.py:116-127,298-301].
+    (a) the view's values == the dense crops, bit for bit, for boxes of every kind (in / across every border, tiny, one
+    exactly 224 wide: no resampling); (b) every border element of the pool is zero, also after a SECOND call with fewer
+    crops and other boxes reused the pool; (c) features via the view == via the dense tensor (the same padded operand
+    bits reach conv1), and the profile shows no pad_nchw; (d) a slice of 3 crops (too few rows for the persistent GEMM:
+    the library unpads and takes the im2col route) == the dense path too."""
+    import numpy as np
+    sd = synthetic_state_dict()
+
+    def make():
+        model, _ = clip.load(sd, max_batch=70)
+        v = model.visual
+        v.positional_embedding = v.interpolate_positional_embedding((14, 14))
+        v.grid = 14
+        v.conv1.stride = (16, 16)
+        v.conv1.padding = (15, 15)
+        v.object_stream = True
+        return v
+
+    a, b = make(), make()
+    b.padded_crops = False
+    rng = np.random.default_rng(4)
+    imgs = [torch.from_numpy(rng.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8)).to(cuda)
+            for ww, hh in ((640, 480), (333, 517), (224, 224))]
+
+    def boxes_for(seed, per):
+        r = np.random.default_rng(seed)
+        out = []
+        for im in imgs:
+            hh, ww = im.shape[:2]
+            bs = [(0, 0, ww, hh), (-20.5, -10.5, ww * 0.6, hh * 0.7), (ww * 0.3, hh * 0.2, ww + 33.2, hh + 5.5),
+                  (ww * 0.45, hh * 0.45, ww * 0.45 + 4.2, hh * 0.45 + 9.7), (0, 0, min(ww, 224), min(hh, 224))]
+            for _ in range(per):
+                x1, y1, side = r.uniform(-30, ww * 0.8), r.uniform(-30, hh * 0.8), r.uniform(4, max(ww, hh))
+                bs.append((x1, y1, x1 + side, y1 + side))
+            out.append([tuple(float(t) for t in bb) for bb in bs])
+        return out
+
+    for seed, per in ((1, 18), (2, 9)):  # 69 crops, then 42 into the same pool
+        boxes = boxes_for(seed, per)
+        va = a.crop_resize_normalize_batch(imgs, boxes, out_dtype=torch.float16)
+        vb = b.crop_resize_normalize_batch(imgs, boxes, out_dtype=torch.float16)
+        n = vb.shape[0]
+        assert va.shape == vb.shape and not va.is_contiguous() and vb.is_contiguous()
+        assert torch.equal(va, vb)
+        pool, pad, hp, ws = next(iter(a._pad_pools.values()))
+        assert (pad, hp, ws) == (15, 254, 256) and pool.shape[0] >= n
+        border = pool.clone()
+        border[:, :, pad:pad + 224, pad:pad + 224] = 0
+        assert not border.any()  # (rows past n keep the previous call's interiors: only the BORDER must be zero)
+        masks = (torch.rand(n, 1, 14, 14, generator=torch.Generator().manual_seed(seed)) < 0.6).half().to(cuda)
+        a.profile(True)
+        ya = a(va, masks, normalize=True, out_dtype=torch.float32)
+        names = {p_['name'] for p_ in a.profile_read() if p_['launches'] > 0}
+        a.profile(False)
+        assert 'pad_nchw' not in names and 'im2col' not in names and 'gemm_conv1' in names, names
+        yb = b(vb, masks, normalize=True, out_dtype=torch.float32)
+        assert torch.equal(ya, yb)
+        # dim-0 slices of the view stay views of the pool; a handful of crops takes the unpad + im2col route
+        assert torch.equal(a(va[40:], masks[40:], normalize=True, out_dtype=torch.float32),
+                           b(vb[40:], masks[40:], normalize=True, out_dtype=torch.float32))
+        a.profile(True)
+        y3 = a(va[5:8], masks[5:8], normalize=True, out_dtype=torch.float32)
+        names = {p_['name'] for p_ in a.profile_read() if p_['launches'] > 0}
+        a.profile(False)
+        assert 'unpad_nchw' in names and 'im2col' in names, names
+        assert torch.equal(y3, b(vb[5:8], masks[5:8], normalize=True, out_dtype=torch.float32))
+    # a dense copy of the view is an ordinary tensor again
+    assert torch.equal(a(va.contiguous(), masks, normalize=True, out_dtype=torch.float32), ya)
+    # a narrow tower (width 128: conv1 does not run the persistent GEMM at any pass size): EVERY pass of a padded-layout
+    # call is unpadded into the library's own scratch — found by tests/fuzz_pipeline.py when that copy went into a
+    # workspace buffer that is smaller than the crops in such a geometry
+    sdt = synthetic_state_dict(**TINY)
+    mt, _, _ = _objects_model(sdt, TINY, max_batch=16)
+    md, _, _ = _objects_model(sdt, TINY, max_batch=16)
+    md.visual.padded_crops = False
+    boxes = boxes_for(3, 12)  # 51 crops: several passes
+    vt = mt.visual.crop_resize_normalize_batch(imgs, boxes, out_dtype=torch.float16)
+    vd = md.visual.crop_resize_normalize_batch(imgs, boxes, out_dtype=torch.float16)
+    assert not vt.is_contiguous() and torch.equal(vt, vd)
+    mk = (torch.rand(vt.shape[0], 1, 14, 14, generator=torch.Generator().manual_seed(9)) < 0.5).half().to(cuda)
+    assert torch.equal(mt.visual(vt, mk, normalize=True, out_dtype=torch.float32),
+                       md.visual(vd, mk, normalize=True, out_dtype=torch.float32))
+
+
 def test_cu_count_option_and_masked_stream(cuda, lib):
     """OAKE_OPT_CU_COUNT sizes the persistent grids for a CU-masked stream (round 3's half-chip lanes experiment,
     oadp_amd/cumask.py): fewer, longer-running blocks walk the same tiles — bit-identical features — and a stream

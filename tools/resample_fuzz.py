@@ -18,8 +18,19 @@ OUT = int(os.environ.get('OUT_SIZE', 224))  # the model's input resolution = the
 model, _ = clip.load(synthetic_state_dict(image_size=OUT, patch_size=32, width=128, layers=1, heads=2, mlp_dim=256,
                                           embed_dim=64), max_batch=2)
 vis = model.visual
+# objects-mode twin (conv1 stride // 2, padding (patch - 1) // 2): its f16 crops go straight into the zero-padded batch
+# conv1 gathers from (resample_v4p_kernel, OAKE_LAYOUT_PADDED) and come back as a strided view of that pool — compared
+# with the dense f16 crops of the plain model, bit for bit, and the pool's border must stay zero
+omodel, _ = clip.load(synthetic_state_dict(image_size=OUT, patch_size=32, width=128, layers=1, heads=2, mlp_dim=256,
+                                           embed_dim=64), max_batch=2)
+ovis = omodel.visual
+ovis.positional_embedding = ovis.interpolate_positional_embedding((ovis.grid * 2,) * 2)
+ovis.grid *= 2
+ovis.conv1.stride = (16, 16)
+ovis.conv1.padding = (15, 15)
+ovis.object_stream = True
 dev = torch.device('cuda:0')
-bad = crops = resizes = 0
+bad = crops = resizes = padded = 0
 for it in range(n):
     r = rng.random()
     if r < 0.15:
@@ -57,6 +68,15 @@ for it in range(n):
         except Exception as e:  # (e.g. a Resize that would exceed the supported size: must be loud, not wrong)
             print('RAISED', (w, h), squash, str(e)[:120])
             continue
+        o16 = vis.crop_resize_normalize_batch([d], [boxes], squash=squash, out_dtype=torch.float16)
+        p16 = ovis.crop_resize_normalize_batch([d], [boxes], squash=squash, out_dtype=torch.float16)
+        if p16.is_contiguous():
+            print('PADDED POOL NOT USED')
+            bad += 1
+        padded += p16.shape[0]
+        if not torch.equal(p16, o16):
+            bad += 1
+            print('MISMATCH padded crops', (w, h), 'squash', squash, int((p16 != o16).sum()))
         for b, o in zip(boxes, out):
             crops += 1
             try:
@@ -77,5 +97,12 @@ for it in range(n):
     if not np.array_equal(got, ref):
         bad += 1
         print('MISMATCH resize', (w, h), '->', (ow, oh), 'max', int(np.abs(got.astype(int) - ref).max()))
-print(f'resample_fuzz seed {seed} (out {OUT}): {n} images, {crops} crops and {resizes} resizes compared with PIL, {bad} mismatches')
+for pool, pad, hp, ws in ovis._pad_pools.values():
+    border = pool.clone()
+    border[:, :, pad:pad + OUT, pad:pad + OUT] = 0
+    if border.any():
+        bad += 1
+        print('PADDED POOL: border not zero', int((border != 0).sum()))
+print(f'resample_fuzz seed {seed} (out {OUT}): {n} images, {crops} crops and {resizes} resizes compared with PIL, '
+      f'{padded} crops through the zero-padded batch compared with the dense ones, {bad} mismatches')
 sys.exit(1 if bad else 0)
