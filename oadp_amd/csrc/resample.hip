@@ -579,38 +579,93 @@ __global__ __launch_bounds__(256) void resample_v4p_kernel(const ResampleJob* __
   }
 }
 
-// Vertical pass to a uint8 HWC image (whole-image resize for the blocks pyramid).
-__global__ __launch_bounds__(256) void resample_v_u8_kernel(const ResampleJob* __restrict__ jobs,
-                                                            const int32_t* __restrict__ coef,
-                                                            const int32_t* __restrict__ bounds,
-                                                            const uint8_t* __restrict__ temp) {
+// Vertical pass to a uint8 HWC image (whole-image resize for the blocks pyramid), four consecutive pixels of one output
+// row per thread (jobs that are not transposed): a tap's 4 x RGB
+// source bytes are 12 contiguous bytes of the intermediate image (resample_v4_kernel's load), and the four result pixels
+// leave as ONE 12-byte store at the pixel's own byte alignment (the pyramid level's rows are 3 * width bytes apart:
+// dword-unaligned in general, which gfx950 serves) instead of twelve single-byte stores.  The last, partial group of a
+// row and transposed jobs go pixel by pixel.  Same integers as Pillow's: bit-identical.
+__global__ __launch_bounds__(256) void resample_v4_u8_kernel(const ResampleJob* __restrict__ jobs,
+                                                             const int32_t* __restrict__ coef,
+                                                             const int32_t* __restrict__ bounds,
+                                                             const uint8_t* __restrict__ temp) {
   const ResampleJob jb = jobs[blockIdx.y];
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= (long)jb.rh * jb.rw) return;
-  // p walks the OUTPUT image row-major: rh x rw, or rw x rh (rows x columns) for a transposed job
-  const int ow = jb.tr ? jb.rh : jb.rw;
-  const int orow = p / ow, ocol = p - (long)orow * ow;
-  const int ry = jb.tr ? ocol : orow, rx = jb.tr ? orow : ocol;
-  const uint8_t* tcol = temp + jb.temp_off + (long)rx * 3;
-  uint8_t* o = jb.u8_out + p * 3;
-  if (jb.ch == jb.rh) {
-    const uint8_t* q = tcol + (long)ry * jb.tstride;
-    o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+  const int ow = jb.tr ? jb.rh : jb.rw, oh = jb.tr ? jb.rw : jb.rh;  // the OUTPUT image: oh rows of ow pixels
+  const int q4 = (ow + 3) >> 2;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)oh * q4) return;
+  const int orow = (int)(t / q4), oc0 = (int)(t - (long)orow * q4) << 2;
+  uint8_t* o = jb.u8_out + ((long)orow * ow + oc0) * 3;
+  if (!jb.tr && oc0 + 4 <= ow) {
+    const int ry = orow, rx0 = oc0;
+    const uint8_t* tcol = temp + jb.temp_off + (long)rx0 * 3;
+    const long rstep = jb.tstride;
+    unsigned w[3];
+    auto load12 = [](const uint8_t* q, unsigned (&ww)[3]) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(q);
+      const unsigned sh = (unsigned)(a & 3);
+      const u32x4_a4 d = *reinterpret_cast<const u32x4_a4*>(a & ~(uintptr_t)3);
+      ww[0] = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+      ww[1] = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+      ww[2] = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+    };
+    typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
+    if (jb.ch == jb.rh) {
+      load12(tcol + (long)ry * rstep, w);
+    } else {
+      const int32_t* k = coef + jb.coefv_off + (long)ry * jb.kv;
+      const int ymin = bounds[jb.boundv_off + 2L * ry], cnt = bounds[jb.boundv_off + 2L * ry + 1];
+      int acc[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) acc[i] = 1 << (kPrecisionBits - 1);
+      for (int tt = 0; tt < cnt; ++tt) {
+        unsigned x[3];
+        load12(tcol + (long)(ymin + tt) * rstep, x);
+        const int kv = k[tt];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] += tap((int)((x[i >> 2] >> (8 * (i & 3))) & 0xffu), kv);
+      }
+      // (the clipped bytes go through an opaque asm before they are packed: hipcc / ROCm 7.2 matches
+      // "two saturated (x >> 22) side by side" to v_ashr_pk_u8_i32 and then ORs bytes 2 and 3 into a register whose upper
+      // half that instruction does not clear — wrong bytes 2 / 3 of every dword, found by tests/test_resample_gpu.py)
+      unsigned b8[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        b8[i] = clip8(acc[i]);
+        asm volatile("" : "+v"(b8[i]));
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w[j] = b8[4 * j] | b8[4 * j + 1] << 8 | b8[4 * j + 2] << 16 | b8[4 * j + 3] << 24;
+    }
+    u32x3_a1 out3;
+    out3[0] = w[0]; out3[1] = w[1]; out3[2] = w[2];
+    *reinterpret_cast<u32x3_a1*>(o) = out3;
     return;
   }
-  const int32_t* k = coef + jb.coefv_off + (long)ry * jb.kv;
-  const int ymin = bounds[jb.boundv_off + 2L * ry], cnt = bounds[jb.boundv_off + 2L * ry + 1];
-  int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
-  for (int t = 0; t < cnt; ++t) {
-    const uint8_t* q = tcol + (long)(ymin + t) * jb.tstride;
-    const int kv = k[t];
-    s0 += tap(q[0], kv);
-    s1 += tap(q[1], kv);
-    s2 += tap(q[2], kv);
+  for (int i = 0; i < 4 && oc0 + i < ow; ++i) {
+    const int ocol = oc0 + i;
+    const int ry = jb.tr ? ocol : orow, rx = jb.tr ? orow : ocol;
+    const uint8_t* tcol = temp + jb.temp_off + (long)rx * 3;
+    uint8_t* op = o + 3 * i;
+    if (jb.ch == jb.rh) {
+      const uint8_t* q = tcol + (long)ry * jb.tstride;
+      op[0] = q[0]; op[1] = q[1]; op[2] = q[2];
+      continue;
+    }
+    const int32_t* k = coef + jb.coefv_off + (long)ry * jb.kv;
+    const int ymin = bounds[jb.boundv_off + 2L * ry], cnt = bounds[jb.boundv_off + 2L * ry + 1];
+    int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
+    for (int tt = 0; tt < cnt; ++tt) {
+      const uint8_t* q = tcol + (long)(ymin + tt) * jb.tstride;
+      const int kv = k[tt];
+      s0 += tap(q[0], kv);
+      s1 += tap(q[1], kv);
+      s2 += tap(q[2], kv);
+    }
+    op[0] = clip8(s0);
+    op[1] = clip8(s1);
+    op[2] = clip8(s2);
   }
-  o[0] = clip8(s0);
-  o[1] = clip8(s1);
-  o[2] = clip8(s2);
 }
 
 // Exact-size crop + ToTensor + Normalize, many images per launch.  One thread = 8 consecutive pixels of
@@ -630,14 +685,33 @@ __global__ __launch_bounds__(256) void crop_normalize_jobs_kernel(const CropJob*
   float v[3][8];
   const bool row_ok = sy >= 0 && sy < jb.height;
   const uint8_t* rowp = jb.img + (size_t)(row_ok ? sy : 0) * jb.width * 3;
+  if (row_ok && sx >= 0 && sx + 8 <= jb.width) {
+    // the eight pixels are 24 contiguous bytes inside the row: one 16-byte and one 8-byte load at whatever alignment the
+    // crop origin has (gfx950 serves unaligned global accesses) instead of 24 single-byte loads — round 5 measured the
+    // kernel at 0.33 of the HBM peak, 5 % of a blocks step
+    typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+    const uint8_t* q = rowp + (size_t)sx * 3;
+    const u32x4_a1 d0 = *reinterpret_cast<const u32x4_a1*>(q);
+    const u32x2_a1 d1 = *reinterpret_cast<const u32x2_a1*>(q + 16);
+    const unsigned w[6] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1]};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int x = sx + i;
-    const bool ok = row_ok && x >= 0 && x < jb.width;  // PIL crop pads with zeros outside the image
-    const uint8_t* px = rowp + (size_t)(ok ? x : 0) * 3;
-    v[0][i] = ok ? (float)px[0] : 0.f;
-    v[1][i] = ok ? (float)px[1] : 0.f;
-    v[2][i] = ok ? (float)px[2] : 0.f;
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int b = 3 * i + c;
+        v[c][i] = (float)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int x = sx + i;
+      const bool ok = row_ok && x >= 0 && x < jb.width;  // PIL crop pads with zeros outside the image
+      const uint8_t* px = rowp + (size_t)(ok ? x : 0) * 3;
+      v[0][i] = ok ? (float)px[0] : 0.f;
+      v[1][i] = ok ? (float)px[1] : 0.f;
+      v[2][i] = ok ? (float)px[2] : 0.f;
+    }
   }
   const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
   const size_t plane = (size_t)out_size * out_size;
@@ -701,7 +775,8 @@ hipError_t launch_resample(const ResampleJob* d_jobs, int njobs, int max_out, lo
     hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((max_chq_rw + 255) / 256), nj), dim3(256), 0, s,
                        jobs, d_coef, d_bounds, d_temp);
     if (out_dtype == DT_U8) {  // whole-image resizes: every job writes its own image
-      hipLaunchKernelGGL(resample_v_u8_kernel, dim3((unsigned)((max_rh_rw + 255) / 256), nj), dim3(256), 0,
+      // (four pixels per thread: at most max_rh_rw / 4 + one partial group per output row <= max_out rows of a job)
+      hipLaunchKernelGGL(resample_v4_u8_kernel, dim3((unsigned)((max_rh_rw / 4 + max_out + 255) / 256), nj), dim3(256), 0,
                          s, jobs, d_coef, d_bounds, d_temp);
       continue;
     }
