@@ -17,7 +17,7 @@ import shutil
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 src, dst = ROOT / 'gpurun_out' / tag, ROOT / 'profiles' / tag
 dst.mkdir(parents=True, exist_ok=True)
 for name in ('session.txt', 'pytest_gpu.txt', 'smoke.txt'):

@@ -20,7 +20,7 @@ import pathlib
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 PEAK_FLOPS, PEAK_HBM, SIMDS, XCDS = 2.5e15, 8e12, 1024, 8
 SLOTS = {'im2col_kernel': 'im2col', 'pad_nchw_kernel': 'pad_nchw', 'embed_ln_pre_kernel': 'embed_ln_pre',
          'gemm_pp_kernelIDF16_Li6E': 'gemm_conv1', 'gemm_pp_kernelIDF16_Li7E': 'gemm_qkv', 'gemm_pp_kernelIDF16_Li8E': 'gemm_c_fc',
@@ -29,7 +29,8 @@ SLOTS = {'im2col_kernel': 'im2col', 'pad_nchw_kernel': 'pad_nchw', 'embed_ln_pre
          # objects mode, 12 layers: 11 launches with the patch stream, then the last layer's object token alone
          'attention_head_kernel': ('attention',) * 11 + ('object_attention',), 'attn_out_kernel': 'attn_out', 'object_attention_kernel': 'object_attention',
          'crop_normalize_jobs_kernel': 'crop_normalize', 'resample_h_kernel': 'resample_h', 'resample_v4_kernel': 'resample_v',
-         'resample_v_kernel': 'resample_v'}
+         'resample_v_kernel': 'resample_v', 'resample_v4p_kernel': 'resample_v', 'resample_v4_u8_kernel': 'resample_v_u8',
+         'resample_coeffs_kernel': 'resample_coeffs'}
 
 
 def slot_of(name, seen):
@@ -100,8 +101,19 @@ for mode_dir in sorted(p for p in (ROOT / 'profiles' / tag).iterdir() if (p / 'l
             rec.update(hbm_read_bytes_corrected=round(rd), hbm_write_bytes=round(wr), hbm_bytes_per_launch=round(rd + wr),
                        hbm_gbps=round((rd + wr) / us / 1e3, 1), hbm_frac_of_peak=round((rd + wr) / (us * 1e-6) / PEAK_HBM, 4))
         table[slot] = rec
-    if mode_dir.name == 'globals' and 'gemm_c_fc' in table:  # A + W + output once, 16-bit: M 12800, N 3072, K 768
-        table['gemm_c_fc']['algorithmic_bytes_per_launch'] = 2 * (12800 * 768 + 3072 * 768 + 12800 * 3072)
+    if mode_dir.name == 'globals':  # operands + output once, 16-bit, at batch 256: T = 12800 rows, C 768, F 3072
+        T, C, F = 12800, 768, 3072
+        alg = {'gemm_c_fc': 2 * (T * C + F * C + T * F),               # A + W + out
+               'gemm_c_proj': 2 * (T * F + C * F + 2 * T * C),          # A + W + x read + x written
+               'gemm_out_proj': 2 * (T * C + C * C + 2 * T * C),
+               'qkv_attn': 2 * (T * C + 3 * C * C + T * C),             # x + the folded in-projection + the attention output
+               'gemm_conv1': 2 * (12544 * 3072 + C * 3072 + 12544 * C),
+               'im2col': 256 * 3 * 224 * 224 * 4 + 12544 * 3072 * 2}
+        for k_, v_ in alg.items():
+            if k_ in table:
+                table[k_]['algorithmic_bytes_per_launch'] = v_
+                if table[k_].get('hbm_bytes_per_launch'):
+                    table[k_]['traffic_over_algorithmic'] = round(table[k_]['hbm_bytes_per_launch'] / v_, 3)
     out[mode_dir.name] = table
     print(mode_dir.name, {k: (v['avg_launch_us_rocprofv3'], v.get('mfma_frac_of_peak'), v.get('hbm_gbps')) for k, v in table.items() if k[0] != '_'})
 (ROOT / 'profiles' / f'{tag}_mfma_util_hbm.json').write_text(json.dumps(out, indent=1))

@@ -3,13 +3,13 @@
 # bench.py's own per-kernel stamps are taken under) — the rocprofv3 --kernel-trace --stats summary of the same
 # command and separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ); plus the two-lane kernel stats for the record.
 # All RAW tool output, under gpurun_out/<tag>/<mode>/, with a session stamp every derived number carries.
-# usage: bash tools/profile_round.sh [tag=r05] [modes="globals blocks objects blocks_1700x1134"] [tests=1]
+# usage: bash tools/profile_round.sh [tag=r06] [modes="globals blocks objects blocks_1700x1134"] [tests=1]
 # (blocks_1700x1134 = --mode blocks --image-size 1700x1134: BASELINE.md 4's 5-level configuration, 245 crops per image)
 # In the container afterwards:  python tools/collect_profiles.py <tag> && python tools/derive_counters.py <tag>
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 MODES=${2:-"globals blocks objects blocks_1700x1134"}
 export OAKE_BENCH_FULL_LINE=1  # bench.json files under profiles/ are the full records (stdout of a plain run is the compact line)
 TESTS=${3:-1}
