@@ -633,7 +633,7 @@ def _run_mode(args, ctx, sub: bool = False) -> dict | None:
     args.image_wh = tuple(int(v) for v in args.image_size.lower().split('x'))
     args.lanes = max(1, int(os.environ.get('OAKE_BENCH_LANES', 2)))
     # torch's intra-op pool for the host half of a step (blocks / objects: bbox math, expand, masks — tiny ops
-    # that each wake one OpenMP thread per core by default; the validators cap it the same way).
+    # that each wake one OpenMP thread per core by default; the validators cap it the same way, docs/history/design_sections_5_6_as_of_round5.md §5.5).
     # The CPU baseline below runs with the full pool.
     torch.set_num_threads(min(ctx['all_threads'], int(os.environ.get('OAKE_BENCH_HOST_THREADS', 8))))
 

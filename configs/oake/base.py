@@ -22,7 +22,7 @@ batch_size = 256
 # (the validator then runs without DataLoader workers: files are read by a prefetch thread of the process,
 # Huffman passes run on `decode_threads` native threads; measured per GPU, files -> .pth: 5-6 k images/s for
 # globals (12 k with two processes per GPU), 85-94 k crops/s for blocks, 23.6 k crops/s for objects —
-# DESIGN.md §5.5, profiles/r02_sweep_1gpu.log)
+# docs/history/design_sections_5_6_as_of_round5.md §5.5, profiles/r02_sweep_1gpu.log)
 decode_threads = 32
 
 # Behaviours of the un-vendored LutingWang/CLIP fork / todd that the reference's sources do not pin

@@ -339,7 +339,7 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               attention output never reaches memory (csrc/attn_out.hip).  Parity-tested; measured
  *                               slower than the two separate launches (39 vs 36 us per layer at batch 256: the
  *                               out_proj weights stream through each CU's 64 B/clk vector-memory path once per
- *                               image): the kernel is in the lab build liboake_hip_lab.so only; the
+ *                               image, docs/history/round4.md): the kernel is in the lab build liboake_hip_lab.so only; the
  *                               production library answers OAKE_ERR_INVALID to a non-zero value.  Default 0.
  *   OAKE_OPT_FUSE_QKV_ATTN      on a 16-bit residual stream, ln_1 + attn.in_proj + softmax(q k^T) v of a layer run as
  *                               ONE persistent kernel: the q | k | v values go from the MFMA accumulators through LDS

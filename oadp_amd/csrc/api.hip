@@ -28,7 +28,7 @@
 #include "../../include/oake_hip.h"
 #include "../../include/oake_hip_debug.h"
 #ifndef OAKE_FUSE_QKV_ATTN_DEFAULT
-#define OAKE_FUSE_QKV_ATTN_DEFAULT 1  // (+2.2 % globals with two lanes, profiles/r05/ab_fuse_qkv_attn_*.log)
+#define OAKE_FUSE_QKV_ATTN_DEFAULT 1  // (+2.2 % globals with two lanes, profiles/r05/ab_fuse_qkv_attn_*.log; docs/history/round5.md)
 #endif
 #include "kernels.h"
 
@@ -1885,7 +1885,7 @@ int oake_debug_ln_qkv_attn(const void* d_x, const float* d_w32, const float* d_g
                            const float* d_bias, void* d_out, int n_img, int l, int heads, int dtype16, void* d_trace,
                            int repeats, void* stream) {
 #if !OAKE_LAB
-  // (the three-image form lost its A/B to the four-image one — DESIGN.md appendix, round 5 — and lives in liboake_hip_lab.so only)
+  // (the three-image form lost its A/B to the four-image one — docs/history/round5.md item 11 — and lives in liboake_hip_lab.so only)
   (void)d_x; (void)d_w32; (void)d_gamma; (void)d_beta; (void)d_bias; (void)d_out; (void)n_img; (void)l; (void)heads;
   (void)dtype16; (void)d_trace; (void)repeats; (void)stream;
   return OAKE_ERR_UNSUPPORTED;
@@ -2000,7 +2000,7 @@ int oake_debug_attn_out(const void* d_qkv, const void* d_w, const float* d_bias,
 int oake_debug_attn_out_trace(const void* d_qkv, const void* d_w, const float* d_bias, void* d_x, float* d_rowpart,
                               int n, int l, int heads, int dtype16, void* d_trace, int repeats, void* stream) {
 #if !OAKE_LAB
-  // (the kernel lost its A/B — DESIGN.md §9.R4 item 4 — and lives in liboake_hip_lab.so only)
+  // (the kernel lost its A/B — docs/history/round4.md item 4 — and lives in liboake_hip_lab.so only)
   (void)d_qkv; (void)d_w; (void)d_bias; (void)d_x; (void)d_rowpart; (void)n; (void)l; (void)heads; (void)dtype16;
   (void)d_trace; (void)repeats; (void)stream;
   return OAKE_ERR_UNSUPPORTED;
@@ -2120,7 +2120,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
       return OAKE_OK;
 #else
       if (value) return fail(h, OAKE_ERR_INVALID, "fuse_attn_out: the fused attention + out_proj kernel is in "
-                             "liboake_hip_lab.so only (measured slower: DESIGN.md 9.R4 item 4)");
+                             "liboake_hip_lab.so only (measured slower: docs/history/round4.md item 4)");
       return OAKE_OK;
 #endif
     case OAKE_OPT_FUSE_QKV_ATTN: {

@@ -1634,7 +1634,7 @@ hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
 //                  5: deep-ring 64x64 (4 waves, 4-slot ring) for the few-hundred-row problems (head,
 //                     CLS rows of the last block, object stream)   6: simple 64x64 (2-slot ring)
 //                  7: one compute wave per SIMD, 160x256, one tile per block (gemm_q4_kernel; experiment)
-//                 11: two workgroups per CU, 160x128 tiles (gemm_duo_kernel; experiment)
+//                 11: two workgroups per CU, 160x128 tiles (gemm_duo_kernel; experiment, docs/history/round2_what_bounds_the_gemm.md item 10)
 //                 12: variant 4 with c_fc's QuickGELU deferred into the next tile's load phases (four phases; OAKE_DEFER_GELU)
 #if OAKE_LAB
 template <typename T, int EPI>

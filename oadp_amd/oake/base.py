@@ -350,7 +350,7 @@ def pick_backend(cuda: bool, gpus_here: int, env=None) -> str:
     """Collective backend for the one counters gather.  RCCL ('nccl') needs a GPU per rank ON THIS NODE:
     torchrun's LOCAL_WORLD_SIZE is the ranks per node (a multi-node run has more ranks in total than any node
     has GPUs, and must still get RCCL); with more ranks than GPUs on a node — several processes per GPU: the host
-    side of the sweep (file reads, Huffman decode, .pth writing) scales with processes, DESIGN.md §5.5 — the
+    side of the sweep (file reads, Huffman decode, .pth writing) scales with processes, docs/history/design_sections_5_6_as_of_round5.md §5.5 — the
     gather goes over gloo.  OAKE_DIST_BACKEND overrides."""
     env = os.environ if env is None else env
     if env.get('OAKE_DIST_BACKEND'):

@@ -217,7 +217,7 @@ def plan_cpus(local_rank: int, local_world: int, allowed: list[int], gpu_pci: li
 
 def pin_cpus(env=None, gpu_pci: list[str] | None = None, sysfs: str = '/sys', apply: bool = True) -> list[int] | None:
     """Per-rank CPU affinity for a multi-rank node: a rank's host side (file reads, Huffman threads, index math, .pth
-    writers: ~11 cores per rank at full rate) stays on cores of the socket its GPU hangs off
+    writers: ~11 cores per rank at full rate, docs/history/round3.md item 9) stays on cores of the socket its GPU hangs off
     (`plan_cpus`) instead of migrating across a 128-256-thread host.  Done ONLY where the number of ranks on this host
     is known (`local_ranks`); OAKE_CPU_AFFINITY=0 switches it off.  The CPUs kept are printed once per process.
     Returns the CPUs kept (None: nothing done)."""

@@ -72,7 +72,7 @@ def test_modes_produce_a_contract_line(mode, extra):
 
 @pytest.mark.gpu
 def test_two_validator_ranks_share_one_gpu(tmp_path):
-    """More ranks than GPUs (the host side of the sweep scales with processes): two full
+    """More ranks than GPUs (docs/history/design_sections_5_6_as_of_round5.md §5.5: the host side of the sweep scales with processes): two full
     validators on the DistributedSampler halves of one image set, one GPU, gloo for the counters gather —
     every image gets its file exactly once."""
     import socket

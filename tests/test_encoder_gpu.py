@@ -712,7 +712,7 @@ def test_profiler_counts_stamped_and_seen_launches(cuda):
 @pytest.mark.parametrize('dtype,tol', [(torch.float16, 1e-3), (torch.bfloat16, 2e-2)])
 def test_encode_image_fused_attention_out_proj(cuda, dtype, tol):
     """The one-kernel attention + out_proj + residual (csrc/attn_out.hip; measured slower, so it lives in the LAB
-    library only: DESIGN.md 9.R4 item 4) against the oracle, against the two-launch form (fuse_attn_out = 0: same
+    library only: docs/history/round4.md item 4) against the oracle, against the two-launch form (fuse_attn_out = 0: same
     arithmetic up to the summation order of out_proj's K dimension), and that it really is the path taken (profile
     slot names).  The product library refuses the option."""
     from oadp_amd import _lib

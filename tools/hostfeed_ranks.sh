@@ -1,5 +1,5 @@
 # Validator ranks sharing ONE GPU, files -> .pth (globals: 1/2/4/8 ranks; blocks: 1/4) with host CPU %: how many ranks
-# the host carries per GPU.  usage: bash tools/hostfeed_ranks.sh [out dir]   (GPU box)
+# the host carries per GPU (docs/history/round3.md item 9).  usage: bash tools/hostfeed_ranks.sh [out dir]   (GPU box)
 set -x
 cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/hostfeed}; mkdir -p $O

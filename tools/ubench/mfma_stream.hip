@@ -1,4 +1,4 @@
-// Micro-benchmark for DESIGN §9 1(a): ONE compute wave per SIMD running a 160x64 wave tile (10 x 4
+// Micro-benchmark for docs/history/round1_notes.md 1(a): ONE compute wave per SIMD running a 160x64 wave tile (10 x 4
 // accumulator tiles, 160 registers) straight through a K-tile — 80 v_mfma_f32_16x16x32_f16 with the
 // fragment reads (ds_read_b128 from a swizzled 128-B-row LDS tile, as gemm.hip) software-pipelined under
 // them — against the production layout's measured 1586 cycles per K-tile (two waves per SIMD in
