@@ -1486,7 +1486,14 @@ TileMap make_tilemap(const GemmArgs& a, int BM, int BN) {
   tmap.tiles_m = (a.M + BM - 1) / BM;
   tmap.tiles_n = (a.N + BN - 1) / BN;
   tmap.nwg = tmap.tiles_m * tmap.tiles_n;
-  int pn = 768 / BN;  // ~768-column panels: a W panel of K=768 is ~1.2 MB of an XCD's 4 MiB L2
+  // N panels of ~1536 columns where K <= 1024 (a W panel of K = 768 is 2.4 MB of an XCD's 4 MiB L2; an XCD's 120 c_fc tiles
+  // are then 20 row tiles x 6 column tiles: 4.9 MB of A + 2.4 MB of W per XCD instead of 9.8 + 1.2), ~768 columns for
+  // longer K.  Round 2 had measured wider panels WORSE (HBM-side reads 118 / 109 / 114 / 175 MB at 3 / 4 / 6 / 12 tile
+  // columns: docs/history/round2_what_bounds_the_gemm.md item 4) — with write-back tile stores, whose 78.6 MB of output
+  // lines shared the L2 with the operands.  With the write-through stores of round 3 the same sweep reads 107.5 / 86.2 /
+  // 71.3 MB (c_fc, profiles/r06/gemm_panel_fetch.txt) and the bench is equal or better in every mode (globals +0.0..0.4 %,
+  // objects +0.2 %, blocks +0.6 %: profiles/r06/ab_gemm_panel_*.log).
+  int pn = (a.K <= 1024 ? 1536 : 768) / BN;
   pn = pn < 1 ? 1 : pn;
   tmap.by_m = 0;
   int panel = a.opts ? a.opts->gemm_panel : 0;
