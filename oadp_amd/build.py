@@ -22,7 +22,7 @@ SOURCES = ['gemm.hip', 'attention.hip', 'qkv_attn_obj.hip', 'rowops.hip', 'resam
 # kernels that lost their A/B: liboake_hip_lab.so only (attn_out: attention + out_proj in one kernel, round 4; qkv_attn: the
 # three-images-per-160-row-tile form of the fused qkv + attention kernel, round 5 — the four-image form of qkv_attn_obj.hip won)
 LAB_ONLY_SOURCES = ['attn_out.hip', 'qkv_attn.hip']
-HEADERS = ['common.h', 'kernels.h', 'attention_head.inc', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
+HEADERS = ['common.h', 'kernels.h', 'attention_head.inc', 'gemm_w8.inc', '../../include/oake_hip.h', '../../include/oake_hip_debug.h']
 ARCH = 'gfx950'
 # instantiations that may spill: the s_memtime-stamped measurement build of attn_out (oake_debug_attn_out_trace), and
 # attn_out itself up to SPILL_SMALL bytes — its out_proj waves sit at the 168-register limit and hipcc parks a few

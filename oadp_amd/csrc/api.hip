@@ -2080,7 +2080,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
     case OAKE_OPT_CLS_LAST: h->cls_last = value ? 1 : 0; return OAKE_OK;
     case OAKE_OPT_GEMM_VARIANT:
       if (value < -1 || !gemm_variant_supported(value))
-        return fail(h, OAKE_ERR_INVALID, "gemm variant " + std::to_string(value) + " is not in this build (production: -1, 0, 4, 5; "
+        return fail(h, OAKE_ERR_INVALID, "gemm variant " + std::to_string(value) + " is not in this build (production: -1, 0, 4, 5, 13; "
                     "the experiments live in liboake_hip_lab.so)");
       h->opts.gemm_variant = value;
       return OAKE_OK;

@@ -74,6 +74,15 @@ struct EpiParams {
 };
 constexpr int kRowParts = 16;  // float2 slots per row (128 B): N <= 1024 residual width
 
+// (sum x, sum x^2) of a row of K values -> LayerNorm's (rstd, -mean rstd), eps = 1e-5 [REF clip's LayerNorm = nn.LayerNorm
+// evaluated in fp32].  One definition for both persistent kernels: their results must agree bit for bit.
+__device__ __forceinline__ float2 ln_rowstat(float s1, float s2, float inv_k) {
+  const float mean = s1 * inv_k;
+  const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + 1e-5f);
+  return make_float2(rstd, -mean * rstd);
+}
+
 struct TileMap {
   int tiles_m, tiles_n, pn, nwg;
   int by_m;  // 0: panels of pn tile-columns, row-major inside;  1: slabs of pn tile-rows, column-major inside
@@ -1124,10 +1133,9 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
               _s2 += _v[i].w;
             }
           }
-          const float _mean = _s1 * ep.inv_k;
-          const float _var = fmaxf(_s2 * ep.inv_k - _mean * _mean, 0.f);
-          st_rstd = rsqrtf(_var + 1e-5f);
-          st_shift = -_mean * st_rstd;
+          const float2 _st = ln_rowstat(_s1, _s2, ep.inv_k);
+          st_rstd = _st.x;
+          st_shift = _st.y;
         }
       }
       if constexpr (A32) {
@@ -1442,6 +1450,7 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
 }
 
 
+#include "gemm_w8.inc"
 #if OAKE_LAB
 #include "gemm_lab_duo.inc"
 #endif
@@ -1596,7 +1605,57 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// c_fc's kernel: the 320 x 256 tile, eight compute waves that issue their own LDS-DMA (gemm_w8.inc; GEMM variant 13).
+// What it takes: a plain matrix A, the 16-bit tile epilogues, and — LayerNorm-folded — seven K-tiles to hand the row
+// statistics over.  Anything else goes to the 160 x 256 kernel.
+inline bool w8_takes(int epi, const GemmArgs& a) {
+  const bool ln = epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN;
+  if (!ln && epi != EPI_T16_BIAS && epi != EPI_T16_GELU && epi != EPI_T16_NONE && epi != EPI_T16_RAW) return false;
+  return a.patch_S == 0 && a.K >= (ln ? 7 : 3) * BK;
+}
+// ... and what the automatic choice gives it: problems whose 320-row tiles fill the chip as well as the 160-row ones
+// do (a 320-row tile costs two of those in this count, 1.78 measured).  At 12 800 rows that is c_fc — N = 3072: 480
+// tiles = two rounds of 256 CUs against four — and not qkv (N = 2304: two rounds against three; measured 56 us
+// against 47, profiles/r06/w8/).
+inline bool w8_preferred(int epi, const GemmArgs& a) {
+  if (!w8_takes(epi, a) || epi == EPI_T16_NONE || epi == EPI_T16_RAW) return false;
+  int num_cu = 0;
+  if (device_cu_count(&num_cu) != hipSuccess || num_cu <= 0) return false;
+  if (a.opts && a.opts->cu_count > 0 && a.opts->cu_count < num_cu) num_cu = a.opts->cu_count;
+  const long tn = (a.N + 255) / 256;
+  const long t320 = (a.M + 319) / 320 * tn, t160 = (a.M + 159) / 160 * tn;
+  return 2 * ((t320 + num_cu - 1) / num_cu) <= (t160 + num_cu - 1) / num_cu;
+}
+
+template <typename T, int EPI>
+hipError_t launch_w8(const GemmArgs& a, hipStream_t s) {
+  constexpr int BM = 320, BN = 256;
+  constexpr int lds = 2 * (BM + BN) * kRowBytes + W8Lds::kBytes;
+  static DynLdsAttr attr;
+  auto kern = gemm_w8_kernel<T, EPI>;
+  if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+  int num_cu = 0;
+  if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
+  if (a.opts && a.opts->cu_count > 0 && a.opts->cu_count < num_cu) num_cu = a.opts->cu_count;
+  if (!w8_takes(EPI, a)) return launch_pp<T, EPI, 160, 256, 2, 4, EpiTraits<EPI>::kLn>(a, s);
+  const TileMap tmap = make_tilemap(a, BM, BN);
+  int grid = (num_cu / 8) * 8;
+  if (grid < 8) grid = 8;
+  const int need = ((tmap.nwg + 7) / 8) * 8;
+  if (grid > need) grid = need;
+  EpiParams ep{a.bias, a.out, a.ldo, a.pos, a.P2, a.L,
+               reinterpret_cast<const float2*>(a.rowstat), a.colsum,
+               reinterpret_cast<float2*>(a.rowpart_out), reinterpret_cast<const float2*>(a.rowpart_in),
+               a.nparts, 1.0f / (float)a.K, 0, 0, 0};
+  OAKE_LAUNCH(kern, dim3(grid), dim3(512), lds, s, reinterpret_cast<const T*>(a.A), reinterpret_cast<const T*>(a.W), a.M,
+              a.N, a.K, ep, tmap);
+  return hipGetLastError();
+}
+
 #if OAKE_LAB
+template <typename T, int EPI>
+hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s);
+
 template <typename T, int EPI, int BM, int BN>
 hipError_t launch_duo(const GemmArgs& a, hipStream_t s) {
   constexpr int lds = 2 * (BM + BN) * kRowBytes + EpiLds::kBytes;
@@ -1649,6 +1708,7 @@ hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
   if constexpr (EpiTraits<EPI>::kNone || EpiTraits<EPI>::kRaw) {  // measurement epilogues: persistent kernels only
     if (variant == 8) return launch_pp<T, EPI, 128, 256, 2, 4>(a, s);
     if (variant == 11) return launch_duo<T, EPI, 160, 128>(a, s);
+    if (variant == 13) return launch_w8<T, EPI>(a, s);
     if constexpr (EpiTraits<EPI>::kNone) {  // (9: the K loop alone in the production schedule, two long phases per K-tile)
       if (variant == 9) return launch_pp<T, EPI, 160, 256, 2, 4, true>(a, s);
     }
@@ -1684,6 +1744,11 @@ hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
       else
         return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     case 10: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);  // four short phases for every epilogue (A/B, cycle stamps)
+    case 13:  // 320 x 256 tile, eight compute waves issuing their own LDS-DMA (gemm_w8_kernel; the 16-bit tile epilogues)
+      if constexpr (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN)
+        return launch_w8<T, EPI>(a, s);
+      else
+        return launch_variant_lab<T, EPI>(4, a, s);
     case 12:  // four phases + the QuickGELU of c_fc deferred into the next tile's load phases (round 6)
       if constexpr (EPI == EPI_T16_GELU_LN || EPI == EPI_T16_GELU)
         return launch_pp<T, EPI, 160, 256, 2, 4, false, false, true>(a, s);
@@ -1708,8 +1773,9 @@ hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
 
 #endif
 
-// The production library: the configurations pick_variant() can select — 0 (simple 128x128: narrow N), 4 (the
-// persistent ping-pong kernel) and 5 (deep-ring 64x64: few-hundred-row problems).  Everything else is in the lab build.
+// The production library: the configurations the automatic choice can make — 0 (simple 128x128: narrow N), 4 (the
+// persistent ping-pong kernel, 160 x 256), 5 (deep-ring 64x64: few-hundred-row problems) and 13 (the 320 x 256 tile of
+// gemm_w8.inc: c_fc).  Everything else is in the lab build.
 template <typename T, int EPI>
 hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
 #if OAKE_LAB
@@ -1720,6 +1786,10 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
   } else
   switch (variant) {
     case 0: return launch_simple<T, EPI, 128, 128, 2, 2>(a, s);
+    case 13:  // the 320 x 256 tile for the 16-bit tile epilogues (c_fc); every other epilogue: as 4
+      if constexpr (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN)
+        return launch_w8<T, EPI>(a, s);
+      [[fallthrough]];
     case 4:  // two long phases per K-tile where the epilogue keeps no tile pending (residual, conv1) and for the
              // LayerNorm-folded epilogues (qkv, c_fc: all of a tile's stores at its end, full lines, written through)
       if (a.patch_f32) return hipErrorInvalidValue;  // (fp32 conv1 gather through the DMA waves' registers: lab build)
@@ -1746,7 +1816,8 @@ int pick_variant(const GemmArgs& a) {
 
 template <typename T>
 hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
-  const int v = pick_variant(a);
+  int v = pick_variant(a);
+  if (v == 4 && !(a.opts && a.opts->gemm_variant >= 0) && w8_preferred(epi, a)) v = 13;
   switch (epi) {
     case EPI_F32_BIAS: return launch_variant<T, EPI_F32_BIAS>(v, a, s);
     case EPI_T16_BIAS: return launch_variant<T, EPI_T16_BIAS>(v, a, s);
@@ -1767,9 +1838,9 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 
 bool gemm_variant_supported(int v) {
 #if OAKE_LAB
-  return v >= -1 && v <= 12;
+  return v >= -1 && v <= 13;
 #else
-  return v == -1 || v == 0 || v == 4 || v == 5;
+  return v == -1 || v == 0 || v == 4 || v == 5 || v == 13;
 #endif
 }
 
@@ -1778,7 +1849,7 @@ bool gemm_uses_persistent(int M, int N, int K, const LaunchOpts* opts) {
   a.M = M; a.N = N; a.K = K;
   a.opts = opts;
   const int v = pick_variant(a);
-  return (v == 4 || v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && K >= 3 * BK;
+  return (v == 4 || v == 8 || v == 9 || v == 10 || v == 11 || v == 12 || v == 13) && K >= 3 * BK;
 }
 
 bool gemm_patch_direct_ok(int image, int patch, int stride, int padding, int M, int N, int K,

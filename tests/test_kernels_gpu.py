@@ -14,7 +14,7 @@ from oadp_amd import _lib
 pytestmark = pytest.mark.gpu
 
 DT = {torch.float16: _lib.OAKE_F16, torch.bfloat16: _lib.OAKE_BF16}
-PROD_GEMM = (-1, 0, 4, 5)  # tile configurations of the production library; the others live in liboake_hip_lab.so
+PROD_GEMM = (-1, 0, 4, 5, 13)  # tile configurations of the production library; the others live in liboake_hip_lab.so
 
 
 def _stream():
@@ -28,7 +28,7 @@ def test_gemm(lib, cuda, dtype, m, n, k):
     _gemm_case(lib, cuda, dtype, m, n, k)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 132, 3072), (12800, 768, 128)])
 def test_gemm_tile_configs(lib, lab, cuda, variant, m, n, k):
     """Every tile configuration (csrc/gemm.hip) on ragged M/N edges."""
@@ -40,11 +40,11 @@ def test_gemm_tile_configs(lib, lab, cuda, variant, m, n, k):
         lib.oake_debug_set_gemm_variant(-1)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize('gelu', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 64), (1350, 768, 768), (50, 2304, 192), (333, 136, 512),
-                                   (12800, 3072, 128), (12800, 3072, 768), (12800, 2048, 192)])
+                                   (12800, 3072, 128), (12800, 3072, 768), (12800, 2048, 192), (5000, 1288, 256)])
 def test_gemm_16bit_epilogues(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     """QKV / c_fc epilogues: bias (+QuickGELU) and the paired-column 16-byte stores."""
     lib = lib if variant in PROD_GEMM else lab
@@ -68,11 +68,12 @@ def test_gemm_16bit_epilogues(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 4, 5, 6, 8, 12])
+@pytest.mark.parametrize('variant', [0, 1, 4, 5, 6, 8, 12, 13])
 @pytest.mark.parametrize('gelu', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (50, 2304, 768), (333, 136, 512),
-                                   (12800, 1024, 256), (12800, 3072, 768), (25600, 1536, 192)])
+                                   (12800, 1024, 256), (12800, 3072, 768), (25600, 1536, 192), (5003, 1288, 448),
+                                   (1000, 520, 768)])
 def test_gemm_layernorm_folded(lib, lab, cuda, variant, gelu, dtype, m, n, k):
     """LayerNorm folded into the consuming GEMM (16-bit residual stream): gamma in W, beta in the
     bias, per-row (rstd, -mean*rstd) applied in the epilogue == GEMM(LayerNorm(x)) in fp32."""
@@ -100,6 +101,49 @@ def test_gemm_layernorm_folded(lib, lab, cuda, variant, gelu, dtype, m, n, k):
         ref = ref * torch.sigmoid(1.702 * ref)
     tol = 3e-3 if dtype == torch.float16 else 2e-2
     torch.testing.assert_close(c.float(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('gelu', [0, 1])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('m,n,k', [(12800, 3072, 768), (25600, 768, 768), (5003, 1288, 448), (640, 520, 768)])
+def test_gemm_320_row_tile_matches_the_160_row_kernel_bit_for_bit(lib, cuda, gelu, dtype, m, n, k):
+    """c_fc runs on the 320 x 256 kernel (variant 13) when its tiles fill the chip and on the 160 x 256 one (variant 4)
+    otherwise — a choice that depends on the row count, so the two must agree in every bit: same MFMA order, the same
+    slot-order sum of the row statistics, the same epilogue arithmetic."""
+    g = torch.Generator(device='cpu').manual_seed(m + n + k + gelu)
+    x = torch.randn(m, k, generator=g) * 1.5 + 0.3
+    x[:, 5] *= 12.0
+    x = x.to(dtype).to(cuda)
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).to(cuda)
+    gamma = (1.0 + 0.3 * torch.randn(k, generator=g)).to(cuda)
+    beta = (0.2 * torch.randn(k, generator=g)).to(cuda)
+    bias = torch.randn(n, generator=g).to(cuda)
+    outs = []
+    for variant in (4, 13):
+        c = torch.full((m, n), float('nan'), dtype=dtype, device=cuda)
+        lib.oake_debug_set_gemm_variant(variant)
+        try:
+            assert lib.oake_debug_ln_gemm16(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+                                            c.data_ptr(), m, n, k, DT[dtype], gelu, _stream()) == 0
+            torch.cuda.synchronize()
+        finally:
+            lib.oake_debug_set_gemm_variant(-1)
+        outs.append(c)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
+    w16 = w.to(dtype)
+    outs = []
+    for variant in (4, 13):
+        c = torch.full((m, n), float('nan'), dtype=dtype, device=cuda)
+        lib.oake_debug_set_gemm_variant(variant)
+        try:
+            assert lib.oake_debug_gemm16(a.data_ptr(), w16.data_ptr(), bias.data_ptr(), c.data_ptr(), m, n, k, DT[dtype], gelu,
+                                         _stream()) == 0
+            torch.cuda.synchronize()
+        finally:
+            lib.oake_debug_set_gemm_variant(-1)
+        outs.append(c)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
 
 
 @pytest.mark.parametrize('variant', [-1, 10])
@@ -497,11 +541,11 @@ def test_production_library_refuses_lab_variants(lib, lab):
     """the product carries only what its own selection can return; the experiments are in the
     lab build, and both say which they are."""
     assert lib.oake_debug_lab_build() == 0 and lab.oake_debug_lab_build() == 1
-    for v in range(-1, 13):
+    for v in range(-1, 14):
         want = _lib.OAKE_OK if v in PROD_GEMM else _lib.OAKE_ERR_UNSUPPORTED
         assert lib.oake_debug_set_gemm_variant(v) == want, v
         assert lab.oake_debug_set_gemm_variant(v) == _lib.OAKE_OK
-    assert lib.oake_debug_set_gemm_variant(13) == lab.oake_debug_set_gemm_variant(13) == _lib.OAKE_ERR_UNSUPPORTED
+    assert lib.oake_debug_set_gemm_variant(14) == lab.oake_debug_set_gemm_variant(14) == _lib.OAKE_ERR_UNSUPPORTED
     lib.oake_debug_set_gemm_variant(-1)
     lab.oake_debug_set_gemm_variant(-1)
     for v in (0, 7, 30, 63, 95, 128, 191, 255, 256, -1):

@@ -5,7 +5,7 @@ Runs the persistent kernel on the LN-free 16-bit epilogues in four forms on the 
     raw    acc -> 16 bit (pack + trickled stores only)
     none   no epilogue at all (accumulators kept live, nothing stored)
 interleaved in one process (rounds x forms), median per form.
-usage: gemm_ablate.py [variants=4,8] [rounds=5]"""
+usage: gemm_ablate.py [variants=4,8] [rounds=5] [rows=12800]"""
 import ctypes as C, sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +16,7 @@ variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '4,8').split(
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 MODES = (('bias', 0), ('gelu', 1), ('raw', 3), ('none', 2))
-m = 12800
+m = int(sys.argv[3]) if len(sys.argv) > 3 else 12800
 for name, n, k in (('c_fc', 3072, 768), ('qkv', 2304, 768), ('out_proj', 768, 768), ('c_proj', 768, 3072)):
     a = (torch.randn(m, k, device=dev) * 0.5).half()
     w = (torch.randn(n, k, device=dev) * k ** -0.5).half()
