@@ -318,7 +318,7 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               rows ln_post reads): K / V projections of all tokens, everything else of
  *                               that block for one row per image.  0 = run the block for every token as
  *                               the reference does (A/B runs, tests).  Default 1.
- *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default); forced: 0, 4, 5, 13 in the production library, 0..13 in
+ *   OAKE_OPT_GEMM_VARIANT       -1 = automatic per shape (default; -2 = the same, 160-row tiles only: A/B runs); forced: 0, 4, 5, 13 in the production library, 0..13 in
  *                               the lab build liboake_hip_lab.so (csrc/gemm.hip).  Other values: OAKE_ERR_INVALID.
  *   OAKE_OPT_GEMM_PANEL         GEMM tile order: 0 = default, n > 0 = N panels of n tiles (row-major inside),
  *                               n < 0 = M slabs of -n tiles (column-major inside).  Default 0.

@@ -107,7 +107,7 @@ OAKE_API int oake_debug_set_attention_variant(int variant);
  * and measurement epilogue that lost its A/B), 0 in the production library, whose oake_debug_set_* / oake_set_option
  * refuse the lab-only values (OAKE_ERR_UNSUPPORTED / OAKE_ERR_INVALID). */
 OAKE_API int oake_debug_lab_build(void);
-/* GEMM configuration: -1 = automatic per shape, 0..13 = forced (see csrc/gemm.hip; production build: -1, 0, 4, 5, 13).
+/* GEMM configuration: -1 = automatic per shape (-2: without the 320-row tile), 0..13 = forced (see csrc/gemm.hip; production build: -1, 0, 4, 5, 13).
  * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel
  * entry points of the calling thread; a handle's own switches are set with oake_set_option. */
 OAKE_API int oake_debug_set_gemm_variant(int variant);

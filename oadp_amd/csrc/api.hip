@@ -2036,7 +2036,7 @@ int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, doubl
 }
 
 int oake_debug_set_gemm_variant(int variant) {
-  if (variant < -1 || !gemm_variant_supported(variant)) return OAKE_ERR_UNSUPPORTED;
+  if (variant < -2 || !gemm_variant_supported(variant)) return OAKE_ERR_UNSUPPORTED;
   t_debug_opts.gemm_variant = variant;
   return OAKE_OK;
 }
@@ -2079,7 +2079,7 @@ int oake_set_option(oake_handle* h, int option, int value) {
   switch (option) {
     case OAKE_OPT_CLS_LAST: h->cls_last = value ? 1 : 0; return OAKE_OK;
     case OAKE_OPT_GEMM_VARIANT:
-      if (value < -1 || !gemm_variant_supported(value))
+      if (value < -2 || !gemm_variant_supported(value))
         return fail(h, OAKE_ERR_INVALID, "gemm variant " + std::to_string(value) + " is not in this build (production: -1, 0, 4, 5, 13; "
                     "the experiments live in liboake_hip_lab.so)");
       h->opts.gemm_variant = value;

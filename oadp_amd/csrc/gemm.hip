@@ -1610,7 +1610,7 @@ hipError_t launch_pp(const GemmArgs& a, hipStream_t s) {
 // statistics over.  Anything else goes to the 160 x 256 kernel.
 inline bool w8_takes(int epi, const GemmArgs& a) {
   const bool ln = epi == EPI_T16_BIAS_LN || epi == EPI_T16_GELU_LN;
-  if (!ln && epi != EPI_T16_BIAS && epi != EPI_T16_GELU && epi != EPI_T16_NONE && epi != EPI_T16_RAW) return false;
+  if (!ln && epi != EPI_T16_BIAS && epi != EPI_T16_GELU && epi != EPI_RESID16 && epi != EPI_T16_NONE && epi != EPI_T16_RAW) return false;
   return a.patch_S == 0 && a.K >= (ln ? 7 : 3) * BK;
 }
 // ... and what the automatic choice gives it: problems whose 320-row tiles fill the chip as well as the 160-row ones
@@ -1637,7 +1637,7 @@ hipError_t launch_w8(const GemmArgs& a, hipStream_t s) {
   int num_cu = 0;
   if (hipError_t e = device_cu_count(&num_cu); e != hipSuccess) return e;
   if (a.opts && a.opts->cu_count > 0 && a.opts->cu_count < num_cu) num_cu = a.opts->cu_count;
-  if (!w8_takes(EPI, a)) return launch_pp<T, EPI, 160, 256, 2, 4, EpiTraits<EPI>::kLn>(a, s);
+  if (!w8_takes(EPI, a)) return launch_pp<T, EPI, 160, 256, 2, 4, EpiTraits<EPI>::kLn || EPI == EPI_RESID16>(a, s);
   const TileMap tmap = make_tilemap(a, BM, BN);
   int grid = (num_cu / 8) * 8;
   if (grid < 8) grid = 8;
@@ -1745,7 +1745,8 @@ hipError_t launch_variant_lab(int variant, const GemmArgs& a, hipStream_t s) {
         return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);
     case 10: return launch_pp<T, EPI, 160, 256, 2, 4>(a, s);  // four short phases for every epilogue (A/B, cycle stamps)
     case 13:  // 320 x 256 tile, eight compute waves issuing their own LDS-DMA (gemm_w8_kernel; the 16-bit tile epilogues)
-      if constexpr (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN)
+      if constexpr (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN ||
+                    EPI == EPI_RESID16)
         return launch_w8<T, EPI>(a, s);
       else
         return launch_variant_lab<T, EPI>(4, a, s);
@@ -1786,8 +1787,9 @@ hipError_t launch_variant(int variant, const GemmArgs& a, hipStream_t s) {
   } else
   switch (variant) {
     case 0: return launch_simple<T, EPI, 128, 128, 2, 2>(a, s);
-    case 13:  // the 320 x 256 tile for the 16-bit tile epilogues (c_fc); every other epilogue: as 4
-      if constexpr (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN)
+    case 13:  // the 320 x 256 tile for the 16-bit tile epilogues (c_fc; out_proj / c_proj); every other epilogue: as 4
+      if constexpr (EPI == EPI_T16_BIAS || EPI == EPI_T16_GELU || EPI == EPI_T16_BIAS_LN || EPI == EPI_T16_GELU_LN ||
+                    EPI == EPI_RESID16)
         return launch_w8<T, EPI>(a, s);
       [[fallthrough]];
     case 4:  // two long phases per K-tile where the epilogue keeps no tile pending (residual, conv1) and for the
@@ -1817,7 +1819,7 @@ int pick_variant(const GemmArgs& a) {
 template <typename T>
 hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
   int v = pick_variant(a);
-  if (v == 4 && !(a.opts && a.opts->gemm_variant >= 0) && w8_preferred(epi, a)) v = 13;
+  if (v == 4 && !(a.opts && a.opts->gemm_variant != -1) && w8_preferred(epi, a)) v = 13;  // (-2: A/B runs without it)
   switch (epi) {
     case EPI_F32_BIAS: return launch_variant<T, EPI_F32_BIAS>(v, a, s);
     case EPI_T16_BIAS: return launch_variant<T, EPI_T16_BIAS>(v, a, s);
@@ -1838,9 +1840,9 @@ hipError_t launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 
 bool gemm_variant_supported(int v) {
 #if OAKE_LAB
-  return v >= -1 && v <= 13;
+  return v >= -2 && v <= 13;
 #else
-  return v == -1 || v == 0 || v == 4 || v == 5 || v == 13;
+  return v == -2 || v == -1 || v == 0 || v == 4 || v == 5 || v == 13;
 #endif
 }
 

@@ -34,7 +34,7 @@ constexpr int kAttentionVariantDefault = 159;  // attention.hip: bits 1 | 2 | 4 
 constexpr int kQkvWalkDefault = 4;             // qkv_attn_obj.hip: tile walk in head blocks of 4 (0 = group-major)
 
 struct LaunchOpts {
-  int gemm_variant = -1;   // -1 = automatic per shape, else a forced tile configuration (csrc/gemm.hip)
+  int gemm_variant = -1;   // -1 = automatic per shape (-2: the same without the 320-row tile), else a forced tile configuration (csrc/gemm.hip)
   int gemm_panel = 0;      // tile order: 0 default, n > 0 N panels of n tiles, n < 0 M slabs of -n tiles
   unsigned long long* gemm_trace = nullptr;  // device buffer for per-tile cycle stamps, or nullptr
   int attention_variant = kAttentionVariantDefault;  // bits: see oake_debug_set_attention_variant

@@ -14,7 +14,7 @@ from oadp_amd import _lib
 pytestmark = pytest.mark.gpu
 
 DT = {torch.float16: _lib.OAKE_F16, torch.bfloat16: _lib.OAKE_BF16}
-PROD_GEMM = (-1, 0, 4, 5, 13)  # tile configurations of the production library; the others live in liboake_hip_lab.so
+PROD_GEMM = (-2, -1, 0, 4, 5, 13)  # tile configurations of the production library; the others live in liboake_hip_lab.so
 
 
 def _stream():
@@ -105,7 +105,8 @@ def test_gemm_layernorm_folded(lib, lab, cuda, variant, gelu, dtype, m, n, k):
 
 @pytest.mark.parametrize('gelu', [0, 1])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize('m,n,k', [(12800, 3072, 768), (25600, 768, 768), (5003, 1288, 448), (640, 520, 768)])
+@pytest.mark.parametrize('m,n,k', [(12800, 3072, 768), (25600, 768, 768), (5003, 1288, 448), (640, 520, 768),
+                                   (12800, 768, 3072), (5003, 512, 448)])
 def test_gemm_320_row_tile_matches_the_160_row_kernel_bit_for_bit(lib, cuda, gelu, dtype, m, n, k):
     """c_fc runs on the 320 x 256 kernel (variant 13) when its tiles fill the chip and on the 160 x 256 one (variant 4)
     otherwise — a choice that depends on the row count, so the two must agree in every bit: same MFMA order, the same
@@ -118,18 +119,19 @@ def test_gemm_320_row_tile_matches_the_160_row_kernel_bit_for_bit(lib, cuda, gel
     gamma = (1.0 + 0.3 * torch.randn(k, generator=g)).to(cuda)
     beta = (0.2 * torch.randn(k, generator=g)).to(cuda)
     bias = torch.randn(n, generator=g).to(cuda)
-    outs = []
-    for variant in (4, 13):
-        c = torch.full((m, n), float('nan'), dtype=dtype, device=cuda)
-        lib.oake_debug_set_gemm_variant(variant)
-        try:
-            assert lib.oake_debug_ln_gemm16(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
-                                            c.data_ptr(), m, n, k, DT[dtype], gelu, _stream()) == 0
-            torch.cuda.synchronize()
-        finally:
-            lib.oake_debug_set_gemm_variant(-1)
-        outs.append(c)
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    if k <= 1024:  # (LayerNorm-folded: the row-statistics slots cover a residual width of 16 x 64 columns)
+        outs = []
+        for variant in (4, 13):
+            c = torch.full((m, n), float('nan'), dtype=dtype, device=cuda)
+            lib.oake_debug_set_gemm_variant(variant)
+            try:
+                assert lib.oake_debug_ln_gemm16(x.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bias.data_ptr(),
+                                                c.data_ptr(), m, n, k, DT[dtype], gelu, _stream()) == 0
+                torch.cuda.synchronize()
+            finally:
+                lib.oake_debug_set_gemm_variant(-1)
+            outs.append(c)
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
     a = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(cuda)
     w16 = w.to(dtype)
     outs = []
@@ -144,9 +146,26 @@ def test_gemm_320_row_tile_matches_the_160_row_kernel_bit_for_bit(lib, cuda, gel
             lib.oake_debug_set_gemm_variant(-1)
         outs.append(c)
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    # the residual epilogue (out_proj / c_proj where a step has 25 600 rows): x and the row-statistics slices
+    if n % 64 == 0 and n <= 1024:  # (the row-statistics slots: 16 slices of 64 columns)
+        x0 = torch.randn(m, n, generator=g).to(dtype).to(cuda)
+        outs = []
+        for variant in (4, 13):
+            x = x0.clone()
+            part = torch.zeros((m, 16, 2), device=cuda)
+            lib.oake_debug_set_gemm_variant(variant)
+            try:
+                assert lib.oake_debug_gemm_resid16(a.data_ptr(), w16.data_ptr(), bias.data_ptr(), x.data_ptr(), part.data_ptr(),
+                                                   m, n, k, DT[dtype], _stream()) == 0
+                torch.cuda.synchronize()
+            finally:
+                lib.oake_debug_set_gemm_variant(-1)
+            outs.append((x, part))
+        assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+        assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
 
 
-@pytest.mark.parametrize('variant', [-1, 10])
+@pytest.mark.parametrize('variant', [-1, 10, 13])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('m,n,k', [(320, 256, 192), (1350, 768, 768), (2250, 768, 3072), (12800, 512, 256),
                                    (333, 136, 512), (50, 768, 768), (41000, 768, 192), (25600, 768, 768)])
@@ -541,7 +560,7 @@ def test_production_library_refuses_lab_variants(lib, lab):
     """the product carries only what its own selection can return; the experiments are in the
     lab build, and both say which they are."""
     assert lib.oake_debug_lab_build() == 0 and lab.oake_debug_lab_build() == 1
-    for v in range(-1, 14):
+    for v in range(-2, 14):
         want = _lib.OAKE_OK if v in PROD_GEMM else _lib.OAKE_ERR_UNSUPPORTED
         assert lib.oake_debug_set_gemm_variant(v) == want, v
         assert lab.oake_debug_set_gemm_variant(v) == _lib.OAKE_OK
