@@ -23,7 +23,8 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 PEAK_FLOPS, PEAK_HBM, SIMDS, XCDS = 2.5e15, 8e12, 1024, 8
 SLOTS = {'im2col_kernel': 'im2col', 'pad_nchw_kernel': 'pad_nchw', 'embed_ln_pre_kernel': 'embed_ln_pre',
-         'gemm_pp_kernelIDF16_Li6E': 'gemm_conv1', 'gemm_pp_kernelIDF16_Li7E': 'gemm_qkv', 'gemm_pp_kernelIDF16_Li8E': 'gemm_c_fc', 'gemm_w8_kernelIDF16_Li8E': 'gemm_c_fc',
+         'gemm_pp_kernelIDF16_Li6E': 'gemm_conv1', 'gemm_pp_kernelIDF16_Li7E': 'gemm_qkv', 'gemm_pp_kernelIDF16_Li8E': 'gemm_c_fc', 'gemm_w8_kernelIDF16_Li8E': 'gemm_c_fc', 'gemm_w8_kernelIDF16_Li7E': 'gemm_qkv',
+         'gemm_w8_kernelIDF16_Li5E': ('gemm_out_proj', 'gemm_c_proj'),  # (the 320-row tile: passes of 25 600 rows)
          'gemm_pp_kernelIDF16_Li5E': ('gemm_out_proj', 'gemm_c_proj'), 'attention_pair_kernel': 'attention',
          'attention_coop_kernel': 'attention', 'qkv_attn_kernel': 'qkv_attn', 'qkv_attn_obj_kernel': 'qkv_attn',
          # objects mode, 12 layers: 11 launches with the patch stream, then the last layer's object token alone
