@@ -357,7 +357,8 @@ OAKE_API int oake_profile_reset(oake_handle* h);
  *                               rows).  set: a bound >= 1; the cap becomes min(value, the cap the handle
  *                               was created with: the workspace is sized for that) — what the reference's
  *                               `mini_batch_size` is: a memory bound on one pass [REF oadp/oake/objects.py:321-331].  A call's crops are cut into
- *                               equal passes under the cap.
+ *                               passes under the cap: full passes and a shorter last one, or equal passes — whichever
+ *                               fills whole rounds of tiles on the device (oake_debug_plan_pass, oake_hip_debug.h).
  *   OAKE_OPT_QKV_WALK           the fused qkv + attention kernel's tile walk inside an XCD (csrc/qkv_attn_obj.hip,
  *                               walk_decode): n > 0 = head blocks of n heads x group blocks of 32 / n groups (a group =
  *                               a crop, or four images), so that one round of an XCD's 32 blocks streams n x 295 KB of

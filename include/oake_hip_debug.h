@@ -107,6 +107,12 @@ OAKE_API int oake_debug_set_attention_variant(int variant);
  * and measurement epilogue that lost its A/B), 0 in the production library, whose oake_debug_set_* / oake_set_option
  * refuse the lab-only values (OAKE_ERR_UNSUPPORTED / OAKE_ERR_INVALID). */
 OAKE_API int oake_debug_lab_build(void);
+/* The pass size oake_encode_image / oake_encode_objects cut a call of n crops into (csrc/api.hip plan_pass_size: the
+ * cheapest of "passes at the cap + a shorter last one" and k, k + 1, k + 2 equal passes by tile rounds on `compute_units`
+ * CUs; cap = the handle's crops per pass, tokens = rows per crop, images_per_attention_tile = 4 for sequences of <= 50
+ * tokens, else 1).  Host arithmetic only: no device is touched. */
+OAKE_API int oake_debug_plan_pass(int cap, int n, int tokens, int images_per_attention_tile, int width, int mlp_dim,
+                                  int heads, int compute_units);
 /* GEMM configuration: -1 = automatic per shape (-2: without the 320-row tile), 0..13 = forced (see csrc/gemm.hip; production build: -1, 0, 4, 5, 13).
  * All oake_debug_set_* switches are THREAD-LOCAL and affect only the handle-less oake_debug_* kernel
  * entry points of the calling thread; a handle's own switches are set with oake_set_option. */

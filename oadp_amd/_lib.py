@@ -95,6 +95,7 @@ DEBUG_SIGNATURES = {
     'oake_debug_set_attention_variant': (_I, [_I]),
     'oake_debug_set_gemm_variant': (_I, [_I]),
     'oake_debug_lab_build': (_I, []),
+    'oake_debug_plan_pass': (_I, [_I] * 8),
     'oake_debug_gemm_resid16': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     'oake_debug_set_gemm_panel': (_I, [_I]),
     'oake_debug_set_qkv_walk': (_I, [_I]),

@@ -326,7 +326,8 @@ class VisionTransformer(_HookPoint):
         return v.value
 
     # crops per encoder pass: the reference's `mini_batch_size` [REF oadp/oake/objects.py:321-331] is a memory bound on
-    # one pass; here a call's crops are cut into equal passes by the library (cap = min(max_batch, ~25.6 k token rows,
+    # one pass; here a call's crops are cut into passes by the library (csrc/api.hip plan_pass_size: full passes + a shorter
+    # one, or equal passes, whichever fills whole rounds of tiles; cap = min(max_batch, ~25.6 k token rows,
     # OAKE_PASS_ROWS) at handle creation) and `pass_limit` lowers that cap — it never raises it
     _pass_limit: int | None = None
 

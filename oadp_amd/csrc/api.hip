@@ -1172,6 +1172,72 @@ void partition_axis(int length, int r, int s, std::vector<int>& out) {
 
 extern "C" {
 
+// How a call's n crops are cut into passes of <= cfg.max_batch crops.  Every pass runs the same kernels on nb * L token
+// rows, and what a pass costs is a matter of tile counts against the chip: the GEMMs walk ceil(rows / 160 or 320) x
+// ceil(N / 256) tiles in rounds of one per CU (gemm.hip: the 320-row kernel where 2 x its rounds <= the 160-row kernel's;
+// a 320-row tile measured at 1.78 of a 160-row one), the fused ln_1 + in_proj + attention kernel one tile per head and group
+// of `per_tile` images.  Candidates: passes at the cap with a shorter last one, and k, k + 1, k + 2 EQUAL passes (k = the
+// fewest that fit) — a short last pass can run the GEMMs on a fraction of the chip, and equal passes can leave every pass
+// with a nearly empty last round: 1728 crops of 50 tokens under 512 go as 3 x 512 + 192 (whole rounds of every kernel),
+// not 4 x 432 (c_proj / out_proj on 80 % of the CUs, the attention kernel's sixth round at 6 %: 12 % more by this count,
+// measured on ONE lane +6 %, profiles/r06/planner/; two lanes fill each other's empty rounds: +0.4 %).  The cheapest wins;
+// ties, and wins below the model's resolution, keep the fewest equal passes.  Cost unit: one K-tile-length of a 160-row
+// GEMM tile (x K); constant factors common to every candidate are left out.
+static int plan_pass_size_core(int cap, int n, int L, int per_tile, int width, int mlp_dim, int heads, int ncu) {
+  if (n <= cap || cap <= 1) return n > 0 ? std::min(n, std::max(cap, 1)) : 1;
+  if (ncu <= 0) ncu = 256;
+  if (per_tile < 1) per_tile = 1;
+  const double C = width, F = mlp_dim;
+  auto rounds = [&](long rows_per_tile, long rows, long N) {
+    const long tiles = (rows + rows_per_tile - 1) / rows_per_tile * ((N + 255) / 256);
+    return (double)((tiles + ncu - 1) / ncu);
+  };
+  auto gemm = [&](long rows, long N, double K) {
+    const double r160 = rounds(160, rows, N), r320 = rounds(320, rows, N);
+    return K * (2 * r320 <= r160 ? 1.78 * r320 : r160);
+  };
+  auto pass = [&](int nb) {
+    const long rows = (long)nb * L;
+    const long attn_tiles = (long)((nb + per_tile - 1) / per_tile) * heads;
+    return gemm(rows, (long)F, C) + gemm(rows, (long)C, F) + gemm(rows, (long)C, C) +
+           1.3 * C * (double)((attn_tiles + ncu - 1) / ncu);
+  };
+  auto total = [&](int per) {
+    double t = 0;
+    for (int b0 = 0; b0 < n; b0 += per) t += pass(std::min(per, n - b0));
+    return t;
+  };
+  const int k0 = (n + cap - 1) / cap;
+  int best = (n + k0 - 1) / k0;
+  double best_cost = total(best);
+  const int cands[3] = {(n + k0) / (k0 + 1), (n + k0 + 1) / (k0 + 2), cap};
+  for (int per : cands) {
+    if (per < 1 || per > cap) continue;
+    const double t = total(per);
+    if (t < best_cost * 0.99) {  // (a candidate has to win by more than the model's resolution)
+      best = per;
+      best_cost = t;
+    }
+  }
+  return best;
+}
+
+static int plan_pass_size(const oake_handle* h, int n, int L, int per_tile) {
+  const oake_config& c = h->cfg;
+  int ncu = 0;
+  if (n > c.max_batch &&
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess)
+    ncu = 0;
+  if (h->opts.cu_count > 0 && (ncu <= 0 || h->opts.cu_count < ncu)) ncu = h->opts.cu_count;
+  return plan_pass_size_core(c.max_batch, n, L, per_tile, c.width, c.mlp_dim, c.heads, ncu);
+}
+
+// (host arithmetic only — tests/test_abi.py runs it without a GPU)
+int oake_debug_plan_pass(int cap, int n, int tokens, int images_per_attention_tile, int width, int mlp_dim, int heads,
+                         int compute_units) {
+  return plan_pass_size_core(cap, n, tokens, images_per_attention_tile, width, mlp_dim, heads, compute_units);
+}
+
 int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n, void* d_out,
                       int out_dtype, int normalize, void* stream) {
   if (!h) return OAKE_ERR_INVALID;
@@ -1192,10 +1258,9 @@ int oake_encode_image(oake_handle* h, const void* d_images, int in_dtype, int n,
   const size_t img_bytes = (size_t)3 * c.image_size * c.image_size * dtype_size(in_dtype);
   const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
 
-  // passes of equal size (600 crops under a cap of 128: 5 x 120, not 4 x 128 + 88 — a short last pass runs the
-  // GEMMs on a fraction of the chip); a crop's result depends on its pass only through the tile shapes the small
+  // the pass size: plan_pass_size() — a crop's result depends on its pass only through the tile shapes the small
   // last-layer GEMMs pick for the pass's row count (rounding: <= 3e-4 on the unit-norm output, tests/test_encoder_gpu.py)
-  const int per_pass = n > 0 ? (n + (n + c.max_batch - 1) / c.max_batch - 1) / ((n + c.max_batch - 1) / c.max_batch) : 1;
+  const int per_pass = plan_pass_size(h, n, L, L <= 50 ? 4 : 1);
   for (int b0 = 0; b0 < n; b0 += per_pass) {
     const int nb = std::min(per_pass, n - b0);
     const int T = nb * L;
@@ -1327,10 +1392,8 @@ int oake_encode_objects(oake_handle* h, const void* d_objects, int in_dtype, con
   const size_t mask_bytes = (size_t)h->p2 * dtype_size(mask_dtype);
   const size_t out_bytes = (size_t)c.embed_dim * dtype_size(out_dtype);
 
-  // passes of equal size (600 crops under a cap of 128: 5 x 120, not 4 x 128 + 88 — a short last pass runs the
-  // GEMMs on a fraction of the chip); a crop's result depends on its pass only through the tile shapes the small
-  // last-layer GEMMs pick for the pass's row count (rounding: <= 3e-4 on the unit-norm output, tests/test_encoder_gpu.py)
-  const int per_pass = n > 0 ? (n + (n + c.max_batch - 1) / c.max_batch - 1) / ((n + c.max_batch - 1) / c.max_batch) : 1;
+  // the pass size: plan_pass_size() (as oake_encode_image)
+  const int per_pass = plan_pass_size(h, n, L, 1);
   for (int b0 = 0; b0 < n; b0 += per_pass) {
     const int nb = std::min(per_pass, n - b0);
     const int T = nb * L;

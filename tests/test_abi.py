@@ -127,3 +127,24 @@ def test_pass_config_maps_the_environment_onto_the_config():
     assert _pass_config(512, {'OAKE_PASS_ROWS': '29800'}) == (512, 29800)
     assert _pass_config(512, {'OAKE_PASS_CROPS': '120'}) == (120, -1)  # the cap in crops, no row cap beside it
     assert _pass_config(64, {'OAKE_PASS_CROPS': '120'}) == (64, -1)
+
+
+def test_pass_planner_host_arithmetic(lib):
+    """How a call's crops are cut into encoder passes (csrc/api.hip plan_pass_size; no GPU involved): never above the cap,
+    never more passes than two beyond the fewest that fit, one pass when everything fits, and the two cases its comment
+    quotes on a 256-CU chip."""
+    plan = lambda cap, n, tokens, per_tile, ncu=256: lib.oake_debug_plan_pass(cap, n, tokens, per_tile, 768, 3072, 12, ncu)
+    assert plan(512, 256, 50, 4) == 256 and plan(512, 512, 50, 4) == 512 and plan(512, 1, 50, 4) == 1
+    # blocks mode, 64 images of 640 x 480 = 1728 crops: three full passes and a short one fill whole rounds of every
+    # kernel; four equal passes of 432 leave c_proj / out_proj on 80 % of the CUs
+    assert plan(512, 1728, 50, 4) == 512
+    # a remainder that would run on a sliver of the chip is not left alone: 513 crops go as two equal passes
+    assert plan(512, 513, 50, 4) == 257
+    # objects mode (197 tokens per crop, cap 129): 2400 proposal crops of 8 images
+    per = plan(129, 2400, 197, 1)
+    assert 100 <= per <= 129
+    for cap, n, tokens, per_tile in [(512, 15680, 50, 4), (129, 601, 197, 1), (64, 1000, 50, 4), (7, 50, 197, 1), (1, 5, 50, 4)]:
+        for ncu in (256, 128, 0):
+            per = plan(cap, n, tokens, per_tile, ncu)
+            k0 = -(-n // cap)
+            assert 1 <= per <= cap and k0 <= -(-n // per) <= k0 + 2, (cap, n, tokens, per, ncu)
