@@ -91,6 +91,13 @@ OAKE_API int oake_debug_cu_census(uint32_t* d_out, int nblocks, int hold_us, voi
  * d_frags16; *flop (host, may be NULL) receives the FLOPs of the launch.  Timed by the caller, it gives the
  * matrix rate the board sustains under its power cap for that operand data (bench.py `roofline.sustained`). */
 OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream);
+/* The same with v_mfma_f32_32x32x16_f16 (`iters` x 10 per wave on the first 7 x 64 x 8 fragments: half the A / B operand
+ * reads per FLOP, twice the accumulator traffic) — tools/mfma_shape_probe.py: which shape the board sustains more of. */
+/* ... and the 16x16x32 stream over a 10 x 4 wave tile (160 accumulator registers, `iters` x 40 MFMAs per wave) in three
+ * orders: 0 = row by row, 1 = serpentine, 2 = column by column (csrc/gemm.hip mfma_probe_order_kernel). */
+OAKE_API int oake_debug_mfma_probe_order(const void* d_frags16, float* d_sink, int iters, int order, double* flop,
+                                         void* stream);
+OAKE_API int oake_debug_mfma_probe_32x32(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream);
 /* Attention variant bits: 1 = ds_read_b64_tr_b16 V fragments (else 16-bit LDS gathers),
  * 2 = 32 queries per wave (else 64), 4 = sequences longer than 64 keys share K / V through LDS between
  * the four waves of a block, 8 = objects mode: the object token's attention rides on an idle wave

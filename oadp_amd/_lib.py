@@ -92,6 +92,8 @@ DEBUG_SIGNATURES = {
     'oake_debug_tr_read': (_I, [_VP, _VP, _VP]),
     'oake_debug_cu_census': (_I, [_VP, _I, _I, _VP]),
     'oake_debug_mfma_probe': (_I, [_VP, _VP, C.c_int, C.POINTER(C.c_double), _VP]),
+    'oake_debug_mfma_probe_order': (_I, [_VP, _VP, C.c_int, C.c_int, C.POINTER(C.c_double), _VP]),
+    'oake_debug_mfma_probe_32x32': (_I, [_VP, _VP, C.c_int, C.POINTER(C.c_double), _VP]),
     'oake_debug_set_attention_variant': (_I, [_I]),
     'oake_debug_set_gemm_variant': (_I, [_I]),
     'oake_debug_lab_build': (_I, []),

@@ -2098,6 +2098,16 @@ int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, doubl
   return dbg(launch_mfma_probe(d_frags16, d_sink, iters, flop, reinterpret_cast<hipStream_t>(stream)));
 }
 
+int oake_debug_mfma_probe_order(const void* d_frags16, float* d_sink, int iters, int order, double* flop, void* stream) {
+  if (d_frags16 == nullptr || d_sink == nullptr || iters < 1 || order < 0 || order > 2) return OAKE_ERR_INVALID;
+  return dbg(launch_mfma_probe_order(d_frags16, d_sink, iters, order, flop, reinterpret_cast<hipStream_t>(stream)));
+}
+
+int oake_debug_mfma_probe_32x32(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream) {
+  if (d_frags16 == nullptr || d_sink == nullptr || iters < 1) return OAKE_ERR_INVALID;
+  return dbg(launch_mfma_probe32(d_frags16, d_sink, iters, flop, reinterpret_cast<hipStream_t>(stream)));
+}
+
 int oake_debug_set_gemm_variant(int variant) {
   if (variant < -2 || !gemm_variant_supported(variant)) return OAKE_ERR_UNSUPPORTED;
   t_debug_opts.gemm_variant = variant;

@@ -1246,7 +1246,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                       \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                   \
             if (!((OAKE_KLOOP_ABLATE & 4) && (ni & 1)))                                     \
-              acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);                      \
+              acc[mi][OAKE_NI_AT(mi, ni, NI)] =                                             \
+                  T16<T>::mfma(bf[OAKE_NI_AT(mi, ni, NI)], af[mi], acc[mi][OAKE_NI_AT(mi, ni, NI)]); \
     if (!PH2) OAKE_PRIO(0);                                                                 \
   } while (0)
   // (after the epilogue, not while it consumes the rows: zeroed early, the accumulators would stay
@@ -1309,7 +1310,8 @@ __global__ __launch_bounds__((WM * WN + 4) * 64) void gemm_pp_kernel(const T* __
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          if (!((OAKE_KLOOP_ABLATE & 4) && (ni & 1))) acc[mi][ni] = T16<T>::mfma(bf1[ni], af1[mi], acc[mi][ni]);
+          if (!((OAKE_KLOOP_ABLATE & 4) && (ni & 1)))
+            acc[mi][OAKE_NI_AT(mi, ni, NI)] = T16<T>::mfma(bf1[OAKE_NI_AT(mi, ni, NI)], af1[mi], acc[mi][OAKE_NI_AT(mi, ni, NI)]);
       OAKE_PRIO(0);
     } else {
     OAKE_LOAD_FRAGS(c_buf, koff0);
@@ -1487,6 +1489,82 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(const f16x8* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
   if (t == 12345.678f) sink[0] = t;  // (keeps the MFMAs alive; never true for the data the probe is given)
+}
+
+// The same probe with v_mfma_f32_32x32x16_f16: a 160 x 64 wave tile as 5 x 2 tiles of 32 x 32 (160 accumulator
+// registers), ten MFMAs of 32 768 FLOP per 16 values of K — half the A / B operand reads per FLOP of the 16x16x32
+// form, twice the accumulator traffic.  (Round 6: does the board sustain a different rate on the other shape?)
+__global__ __launch_bounds__(512) void mfma_probe32_kernel(const f16x8* __restrict__ frags, float* sink, int iters) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  const int lane = threadIdx.x & 63;
+  f16x8 af[5], bf[2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) af[i] = frags[i * 64 + lane];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bf[j] = frags[(5 + j) * 64 + lane];
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+  if (t == 12345.678f) sink[0] = t;
+}
+
+// ... and the ORDER of a wave's MFMAs over its 10 x 4 tiles of 16 x 16 (gemm_w8_kernel's wave tile, 160 accumulator
+// registers): 0 = row by row (consecutive MFMAs share the A fragment; at a row change both operands change), 1 = serpentine
+// (every consecutive pair shares one operand), 2 = column by column (shares the B fragment, ten MFMAs per column).
+// The accumulation order of every tile is the same in all three: a power question only.
+template <int ORDER>
+__global__ __launch_bounds__(512) void mfma_probe_order_kernel(const f16x8* __restrict__ frags, float* sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  f16x8 af[10], bf[4];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) af[i] = frags[(i % 9) * 64 + lane] + frags[((i + 3) % 9) * 64 + lane];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bf[j] = frags[(5 + j) * 64 + lane];
+  f32x4 acc[10][4];
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (ORDER == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = (ORDER == 1 && (i & 1)) ? 3 - jj : jj;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (t == 12345.678f) sink[0] = t;
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -1868,6 +1946,26 @@ bool gemm_patch_padded_ok(int patch, int stride, int M, int N, int K, const Laun
   // origins (multiples of the stride) and the 8-pixel chunks must stay 16-byte aligned
   return patch % 8 == 0 && stride % 8 == 0 && BK % patch == 0 && (patch * patch) % BK == 0 &&
          K == 3 * patch * patch && gemm_uses_persistent(M, N, K, opts);
+}
+
+hipError_t launch_mfma_probe_order(const void* d_frags, float* d_sink, int iters, int order, double* flop, hipStream_t s) {
+  int cus = 0;
+  if (hipError_t e = device_cu_count(&cus); e != hipSuccess) return e;
+  const f16x8* f = reinterpret_cast<const f16x8*>(d_frags);
+  if (order == 0) OAKE_LAUNCH(mfma_probe_order_kernel<0>, dim3(cus), dim3(512), 0, s, f, d_sink, iters);
+  else if (order == 1) OAKE_LAUNCH(mfma_probe_order_kernel<1>, dim3(cus), dim3(512), 0, s, f, d_sink, iters);
+  else if (order == 2) OAKE_LAUNCH(mfma_probe_order_kernel<2>, dim3(cus), dim3(512), 0, s, f, d_sink, iters);
+  else return hipErrorInvalidValue;
+  if (flop != nullptr) *flop = (double)cus * 8 * 40 * 16384.0 * (double)iters;
+  return hipGetLastError();
+}
+
+hipError_t launch_mfma_probe32(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s) {
+  int cus = 0;
+  if (hipError_t e = device_cu_count(&cus); e != hipSuccess) return e;
+  OAKE_LAUNCH(mfma_probe32_kernel, dim3(cus), dim3(512), 0, s, reinterpret_cast<const f16x8*>(d_frags), d_sink, iters);
+  if (flop != nullptr) *flop = (double)cus * 8 * 10 * 32768.0 * (double)iters;
+  return hipGetLastError();
 }
 
 hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s) {

@@ -5,6 +5,15 @@
 
 #include <string>
 
+// Order of a wave's MFMAs over its MI x NI tiles inside one K-step: 0 = row by row (at a row change both operands of
+// consecutive MFMAs change), 1 = serpentine (every consecutive pair shares one operand fragment).  Every tile's own
+// accumulation order is unchanged: results are bit-identical; the board's power is not (tools/mfma_shape_probe.py:
+// the register-only stream sustains ~1.95 PFLOP/s serpentine against ~1.89 row by row on random operands).
+#ifndef OAKE_MFMA_ORDER
+#define OAKE_MFMA_ORDER 1
+#endif
+#define OAKE_NI_AT(mi_, ni_, NI_) ((OAKE_MFMA_ORDER == 1 && ((mi_) & 1)) ? (NI_) - 1 - (ni_) : (ni_))
+
 namespace oake {
 
 // 16-bit operand type selector (matches OAKE_F16 / OAKE_BF16 in include/oake_hip.h)
@@ -287,5 +296,7 @@ hipError_t launch_tr_read_probe(const uint16_t* in, uint16_t* out, hipStream_t s
 hipError_t launch_cu_census(unsigned* out, int nblocks, int hold_us, hipStream_t s);
 // register-only MFMA stream on every SIMD (gemm.hip): d_frags = 9 x 64 x 8 halves, *flop = work of the launch
 hipError_t launch_mfma_probe(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s);
+hipError_t launch_mfma_probe_order(const void* d_frags, float* d_sink, int iters, int order, double* flop, hipStream_t s);
+hipError_t launch_mfma_probe32(const void* d_frags, float* d_sink, int iters, double* flop, hipStream_t s);  // 32x32x16 form
 
 }  // namespace oake

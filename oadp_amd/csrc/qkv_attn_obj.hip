@@ -449,7 +449,8 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][OAKE_NI_AT(mi, ni, NI)] = T16<T>::mfma(bf[OAKE_NI_AT(mi, ni, NI)], af[mi], acc[mi][OAKE_NI_AT(mi, ni, NI)]);
       __builtin_amdgcn_s_setprio(0);
       QO_BAR();
 #pragma unroll
@@ -462,7 +463,8 @@ __device__ __forceinline__ void obj_compute_wave(char* smem, int tid, int wid, c
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T16<T>::mfma(bf[ni], af[mi], acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][OAKE_NI_AT(mi, ni, NI)] = T16<T>::mfma(bf[OAKE_NI_AT(mi, ni, NI)], af[mi], acc[mi][OAKE_NI_AT(mi, ni, NI)]);
       __builtin_amdgcn_s_setprio(0);
       const bool last = kt == nk - 1;
       if (!last) c_buf = c_buf == kLNStage - 1 ? 0 : c_buf + 1;
