@@ -94,7 +94,8 @@ OAKE_API int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int ite
 /* The same with v_mfma_f32_32x32x16_f16 (`iters` x 10 per wave on the first 7 x 64 x 8 fragments: half the A / B operand
  * reads per FLOP, twice the accumulator traffic) — tools/mfma_shape_probe.py: which shape the board sustains more of. */
 /* ... and the 16x16x32 stream over a 10 x 4 wave tile (160 accumulator registers, `iters` x 40 MFMAs per wave) in three
- * orders: 0 = row by row, 1 = serpentine, 2 = column by column (csrc/gemm.hip mfma_probe_order_kernel). */
+ * orders: 0 = row by row, 1 = serpentine, 2 = column by column, 3 = column by column serpentine (csrc/gemm.hip
+ * mfma_probe_order_kernel). */
 OAKE_API int oake_debug_mfma_probe_order(const void* d_frags16, float* d_sink, int iters, int order, double* flop,
                                          void* stream);
 OAKE_API int oake_debug_mfma_probe_32x32(const void* d_frags16, float* d_sink, int iters, double* flop, void* stream);

@@ -2099,7 +2099,7 @@ int oake_debug_mfma_probe(const void* d_frags16, float* d_sink, int iters, doubl
 }
 
 int oake_debug_mfma_probe_order(const void* d_frags16, float* d_sink, int iters, int order, double* flop, void* stream) {
-  if (d_frags16 == nullptr || d_sink == nullptr || iters < 1 || order < 0 || order > 2) return OAKE_ERR_INVALID;
+  if (d_frags16 == nullptr || d_sink == nullptr || iters < 1 || order < 0 || order > 3) return OAKE_ERR_INVALID;
   return dbg(launch_mfma_probe_order(d_frags16, d_sink, iters, order, flop, reinterpret_cast<hipStream_t>(stream)));
 }
 

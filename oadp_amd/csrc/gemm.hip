@@ -1544,11 +1544,14 @@ __global__ __launch_bounds__(512) void mfma_probe_order_kernel(const f16x8* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < iters; ++it) {
-    if constexpr (ORDER == 2) {
+    if constexpr (ORDER == 2 || ORDER == 3) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 10; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int ii = 0; ii < 10; ++ii) {
+          const int i = (ORDER == 3 && (j & 1)) ? 9 - ii : ii;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
     } else {
 #pragma unroll
       for (int i = 0; i < 10; ++i)
@@ -1955,6 +1958,7 @@ hipError_t launch_mfma_probe_order(const void* d_frags, float* d_sink, int iters
   if (order == 0) OAKE_LAUNCH(mfma_probe_order_kernel<0>, dim3(cus), dim3(512), 0, s, f, d_sink, iters);
   else if (order == 1) OAKE_LAUNCH(mfma_probe_order_kernel<1>, dim3(cus), dim3(512), 0, s, f, d_sink, iters);
   else if (order == 2) OAKE_LAUNCH(mfma_probe_order_kernel<2>, dim3(cus), dim3(512), 0, s, f, d_sink, iters);
+  else if (order == 3) OAKE_LAUNCH(mfma_probe_order_kernel<3>, dim3(cus), dim3(512), 0, s, f, d_sink, iters);
   else return hipErrorInvalidValue;
   if (flop != nullptr) *flop = (double)cus * 8 * 40 * 16384.0 * (double)iters;
   return hipGetLastError();

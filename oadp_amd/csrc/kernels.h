@@ -8,7 +8,7 @@
 // Order of a wave's MFMAs over its MI x NI tiles inside one K-step: 0 = row by row (at a row change both operands of
 // consecutive MFMAs change), 1 = serpentine (every consecutive pair shares one operand fragment).  Every tile's own
 // accumulation order is unchanged: results are bit-identical; the board's power is not (tools/mfma_shape_probe.py:
-// the register-only stream sustains ~1.95 PFLOP/s serpentine against ~1.89 row by row on random operands).
+// the register-only stream sustains 1.94 PFLOP/s serpentine against 1.90 row by row on random operands).
 #ifndef OAKE_MFMA_ORDER
 #define OAKE_MFMA_ORDER 1
 #endif

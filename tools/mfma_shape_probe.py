@@ -19,7 +19,7 @@ def ordered(order):
     return lambda f, sk, it, fl, st: lib.oake_debug_mfma_probe_order(f, sk, it, order, fl, st)
 shapes = {'16x16x32': (lib.oake_debug_mfma_probe, 4000), '32x32x16': (lib.oake_debug_mfma_probe_32x32, 4000),
           '16x16x32 10x4 rows': (ordered(0), 2000), '16x16x32 10x4 serpentine': (ordered(1), 2000),
-          '16x16x32 10x4 columns': (ordered(2), 2000)}
+          '16x16x32 10x4 columns': (ordered(2), 2000), '16x16x32 10x4 col-serpentine': (ordered(3), 2000)}
 for rnd in range(rounds):
     for dname, f in data.items():
         for sname, (fn, iters) in shapes.items():
@@ -35,4 +35,5 @@ for rnd in range(rounds):
             burst(); t0 = time.time(); series = []
             while time.time() - t0 < secs:
                 series.append(burst())
-            print(f'round {rnd} {dname:6s} {sname:26s}: first {series[0]:7.1f} ... last three {" ".join(f"{x:7.1f}" for x in series[-3:])} TFLOP/s', flush=True)
+            import statistics
+            print(f'round {rnd} {dname:6s} {sname:30s}: first {series[0]:7.1f} ... last three {" ".join(f"{x:7.1f}" for x in series[-3:])}  mean {statistics.mean(series[1:]):7.1f} TFLOP/s', flush=True)
