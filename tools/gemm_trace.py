@@ -34,6 +34,17 @@ trace = torch.zeros(4096 + 512, dtype=torch.int64, device=dev)
 lib.oake_debug_set_gemm_trace(C.c_void_p(trace.data_ptr()))
 run(); torch.cuda.synchronize()
 lib.oake_debug_set_gemm_trace(None)
+if len(sys.argv) > 5 and int(sys.argv[5]) == 13:  # gemm_w8_kernel: per-phase sums (gemm_w8.inc W8_STAMP)
+    t = trace[:2048].view(64, 2, 16).cpu()
+    names = ('LOAD0', 'bar', 'MFMA0', 'bar', 'LOAD1', 'bar', 'MFMA1+wait', 'bar', 'entry+epilogues')
+    for b in (0, 7, 40):
+        for grp in (0, 1):
+            r = t[b, grp]; nkt = int(r[15])
+            if nkt == 0: continue
+            per = [int(r[i]) / nkt for i in range(8)]
+            print(f'  block {b} group {grp}: {nkt} K-tiles; cycles per K-tile ' + ' | '.join(f'{n} {c:.0f}' for n, c in zip(names, per))
+                  + f' = {sum(per):.0f}; entry + epilogues {int(r[8])} in all')
+    sys.exit(0)
 wc = trace[4096:].view(256, 2).cpu(); wc = wc[wc[:, 0] > 0]
 if len(wc) == 0:
     sys.exit(0)  # a kernel without cycle stamps
